@@ -1,0 +1,181 @@
+/*
+ * msk144hip - C ABI of the MI355X-native MSK144 hot path (libmsk144hip.so).
+ *
+ * The reference (alexander-sholohov/msk144cudecoder @ 2024_10_08) has no plugin/FFI interface: its
+ * only external boundary is the process (raw samples on stdin, text on stdout).  This ABI is cut
+ * along the reference's internal seams so that its main loop can call it instead of its own CUDA:
+ *
+ *   msk144_create            MSK144SearchContext ctor + ResultKeeper::init + LDPCContext::init +
+ *                            Analytic(8192)                       msk_context.cuh:23-38, main.cu:211-226
+ *   msk144_submit_audio      rms normalise, int16->complex, apply_shift_filter_shift<<<1,32>>> or
+ *                            Analytic::execute                    main.cu:300-332
+ *   msk144_submit_iq         int8 I/Q -> complex, apply_filter<<<1,32>>>   main.cu:365-380
+ *   msk144_decode            clear_result + scan_kernel + softbits_kernel + index_kernel +
+ *                            ldpc_kernel                          main.cu:461-468
+ *   msk144_results           get_all_results() + the is_message_present filter of the host loop
+ *                                                                 main.cu:477-484
+ *   msk144_segment_power     the 8 segment powers SNRTracker::process_data sums from the analytic
+ *                            window                               snr_tracker.cu:21-37, main.cu:388
+ *   msk144_dump_candidates   the raw ResultItem array (parity/debug)     result_keeper.cuh:17-32,123-130
+ *   msk144_destroy           ~MSK144SearchContext / deinit        msk_context.cuh:81-120
+ *
+ * One handle = one device + one HIP stream + `channels` independent input streams decoded per call
+ * (the reference decodes one).  Plain pointers and sizes only; no exceptions cross the boundary:
+ * every entry returns 0 or a negative MSK144_E* code, msk144_last_error() gives the text.
+ * Handles are independent of each other; a handle is not re-entrant.
+ */
+#ifndef MSK144HIP_H
+#define MSK144HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSK144_WINDOW_SAMPLES 5184 /* 6 frames of 864 samples (common.h:15) */
+#define MSK144_HOP_SAMPLES 2592    /* 50 % overlap (main.cu:284) */
+#define MSK144_CODE_BITS 128
+#define MSK144_MESSAGE_BITS 77
+
+enum
+{
+    MSK144_OK = 0,
+    MSK144_EINVAL = -1,   /* bad argument / parameter */
+    MSK144_EHIP = -2,     /* HIP runtime error (text in msk144_last_error) */
+    MSK144_ENOMEM = -3,   /* device or host allocation failed */
+    MSK144_ESTATE = -4,   /* call out of order (e.g. decode before submit) */
+    MSK144_EOVERFLOW = -5 /* more decodes than max_results; results truncated */
+};
+
+/* msk144_decode_stages bits, in launch order (main.cu:463-467) */
+enum
+{
+    MSK144_STAGE_SCAN = 1,
+    MSK144_STAGE_SOFTBITS = 2,
+    MSK144_STAGE_INDEX = 4,
+    MSK144_STAGE_LDPC = 8,
+    MSK144_STAGE_COLLECT = 16,
+    MSK144_STAGE_ALL = 31
+};
+
+/* indices into msk144_stage_times */
+enum
+{
+    MSK144_T_FRONTEND = 0,
+    MSK144_T_SCAN = 1,
+    MSK144_T_SOFTBITS = 2,
+    MSK144_T_INDEX = 3,
+    MSK144_T_LDPC = 4,
+    MSK144_T_COLLECT = 5,
+    MSK144_T_COUNT = 6
+};
+
+typedef struct msk144_params
+{
+    float center_hz;        /* --center-frequency (1500 audio / 0 IQ) */
+    float width_hz;         /* --search-width  (200) */
+    float step_hz;          /* --search-step   (2)   */
+    int32_t scan_depth;     /* --scan-depth    (4), clamped to 1..8 like msk_context.cuh:29-33 */
+    int32_t nbadsync_threshold; /* --nbadsync-threshold (1) */
+    int32_t read_mode;      /* --read-mode: 1 = int16 audio, 2 = int8 I/Q */
+    int32_t analytic_method;/* --analytic-method: 1 = FFT, 2 = shift-filter-shift (audio only) */
+    int32_t channels;       /* independent streams decoded per call (reference: 1) */
+    int32_t device;         /* HIP device ordinal */
+    int32_t max_results;    /* capacity of the compact result list; 0 = default */
+} msk144_params;
+
+/* One accepted decode (CRC ok, < 18 hard errors), fields as the reference's host loop consumes them
+ * (main.cu:484-522). */
+typedef struct msk144_result
+{
+    int32_t channel;
+    int32_t item;            /* k = block_idx*D*8 + pattern_idx*8 + slot inside the channel */
+    float f0;                /* Hz */
+    int32_t pattern_idx;
+    int32_t num_avg;
+    uint32_t pos;
+    float xb;
+    int32_t nbadsync;
+    int32_t ldpc_iterations;
+    int32_t ldpc_hard_errors;
+    uint8_t message[10];     /* 77 payload bits, MSB first, zero padded */
+    uint8_t reserved[2];
+} msk144_result;
+
+/* Same layout as the reference's ResultKeeper::ResultItem (result_keeper.cuh:17-32), 632 bytes. */
+typedef struct msk144_candidate
+{
+    uint32_t block_idx;
+    uint32_t pattern_idx;
+    uint32_t pos;
+    float f0;
+    int32_t nbadsync;
+    float xb;
+    int32_t num_avg;
+    float softbits_wo_sync[128];
+    uint8_t is_message_present;
+    int32_t ldpc_num_iterations;
+    int32_t ldpc_num_hard_errors;
+    char message[77];
+} msk144_candidate;
+
+typedef struct msk144_handle msk144_handle;
+
+/* defaults exactly as main.cu:122-133 (NOT the help text) */
+void msk144_default_params(msk144_params* p);
+
+int msk144_create(const msk144_params* params, msk144_handle** out);
+void msk144_destroy(msk144_handle* h);
+/* h may be NULL: error text of the last failed msk144_create on this thread */
+const char* msk144_last_error(const msk144_handle* h);
+
+/* F frequency hypotheses, D patterns, items per channel = F*D*8 */
+int msk144_geometry(const msk144_handle* h, int32_t* num_freqs, int32_t* scan_depth, int32_t* items_per_channel);
+int msk144_frequency(const msk144_handle* h, int32_t block_idx, float* hz);
+
+/* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the handle's own stream. */
+int msk144_set_stream(msk144_handle* h, void* hip_stream);
+
+/* Front end.  Host buffers are copied H2D on the handle's stream; *_device variants take device
+ * pointers that must stay valid until the front-end kernel has run.
+ *   audio: int16 [channels][5184];   iq: int8 [channels][2*5184] interleaved I,Q. */
+int msk144_submit_audio(msk144_handle* h, const int16_t* windows);
+int msk144_submit_iq(msk144_handle* h, const int8_t* windows);
+int msk144_submit_audio_device(msk144_handle* h, const int16_t* d_windows);
+int msk144_submit_iq_device(msk144_handle* h, const int8_t* d_windows);
+/* bypass the front end: complex64 (re,im) [channels][5184], host memory (parity tests) */
+int msk144_submit_analytic(msk144_handle* h, const float* windows);
+
+/* Asynchronous: enqueues the kernels and returns. */
+int msk144_decode(msk144_handle* h);
+int msk144_decode_stages(msk144_handle* h, uint32_t stages);
+int msk144_synchronize(msk144_handle* h);
+
+/* Waits for the decode, copies the compact result list.  *n = number of decodes (<= cap copied). */
+int msk144_results(msk144_handle* h, msk144_result* out, int32_t cap, int32_t* n);
+int msk144_result_count(msk144_handle* h, int32_t* n);
+/* device-side list for callers that gather on the GPU (RCCL): records + count stay valid until the
+ * next decode */
+int msk144_results_device(msk144_handle* h, const msk144_result** d_records, const int32_t** d_count);
+
+int msk144_segment_power(msk144_handle* h, float* out /*[channels][8]*/);
+
+/* parity / debug */
+int msk144_dump_analytic(msk144_handle* h, int32_t channel, float* out /*[5184][2]*/);
+int msk144_dump_candidates(msk144_handle* h, int32_t channel, msk144_candidate* out /*[items_per_channel]*/);
+int msk144_dump_indexes(msk144_handle* h, int32_t channel, int32_t* out /*[items_per_channel]*/, int32_t* n);
+/* overwrite a channel's candidate store (pos, nbadsync, softbits) so later stages can be run on
+ * known inputs */
+int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candidate* items);
+
+/* per-stage device time (HIP events recorded on the decode stream around every launch), averaged
+ * over the launches since the last reset; samples[s] = launches of stage s that were measured */
+int msk144_set_profiling(msk144_handle* h, int32_t enable);
+int msk144_stage_times(msk144_handle* h, float* avg_ms /*[MSK144_T_COUNT]*/, int32_t* samples /*[MSK144_T_COUNT] or NULL*/, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MSK144HIP_H */

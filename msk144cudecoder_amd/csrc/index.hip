@@ -1,0 +1,159 @@
+// index: order-preserving compaction of candidates whose sync words disagree in at most
+// `nbadsync_threshold` bits, and collect: the same compaction over accepted decodes.
+//
+// Replaces index_kernel (index_kernel.cuh:7-76), where thread 0 of a single
+// 64-thread block walks every flag serially.  Here one 1024-thread workgroup per channel turns each
+// 64-item group into a __ballot mask, prefix-sums the 16 per-wave popcounts through LDS and writes
+// idx[ch][0..n) in ascending item order - the same list, built by wave-wide ballots.
+#include "msk144_kernels.h"
+#include "wave64.h"
+
+#include "../../include/msk144hip.h"
+
+namespace msk144
+{
+
+namespace
+{
+
+constexpr int kIdxThreads = 1024;
+constexpr int kIdxWaves = kIdxThreads / 64;
+
+// Ordered compaction helper: returns this thread's output slot (or -1) for `flag`, advancing `base`
+// (workgroup-uniform running count).  All threads of the workgroup must call it.
+__device__ __forceinline__ int ordered_slot(bool flag, int& base, int* s_wave_count)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if(lane == 0) s_wave_count[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for(int w = 0; w < kIdxWaves; w++)
+    {
+        const int c = s_wave_count[w];
+        if(w < wave) before += c;
+        total += c;
+    }
+    const int slot = flag ? base + before + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    base += total;
+    __syncthreads();
+    return slot;
+}
+
+__global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st)
+{
+    __shared__ int s_wave_count[kIdxWaves];
+    const int ch = blockIdx.x;
+    const size_t off = static_cast<size_t>(ch) * st.K;
+    const int32_t* __restrict__ nbad = st.nbadsync + off;
+    int32_t* __restrict__ out = st.idx + off;
+    int base = 0;
+    for(int k0 = 0; k0 < st.K; k0 += kIdxThreads)
+    {
+        const int k = k0 + threadIdx.x;
+        bool flag = false;
+        if(k < st.K)
+        {
+            flag = nbad[k] <= st.nbadsync_threshold;
+            st.dec_flag[off + k] = 0;  // clear_result (result_keeper.cuh:61-73) for the fields LDPC may set
+        }
+        const int slot = ordered_slot(flag, base, s_wave_count);
+        if(slot >= 0) out[slot] = k;
+    }
+    if(threadIdx.x == 0) st.n_idx[ch] = base;
+}
+
+// ---- collect: accepted decodes -> compact msk144_result records, ordered by (channel, item) ----
+__global__ __launch_bounds__(kIdxThreads) void collect_count_kernel(const DeviceStore st)
+{
+    __shared__ int s_wave_count[kIdxWaves];
+    const int ch = blockIdx.x;
+    const size_t off = static_cast<size_t>(ch) * st.K;
+    int cnt = 0;
+    for(int k = threadIdx.x; k < st.K; k += kIdxThreads) cnt += st.dec_flag[off + k] ? 1 : 0;
+    // wave reduce
+    for(int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
+    if((threadIdx.x & 63) == 0) s_wave_count[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+        int total = 0;
+        for(int w = 0; w < kIdxWaves; w++) total += s_wave_count[w];
+        st.dec_count[ch] = total;
+    }
+}
+
+__global__ __launch_bounds__(kIdxThreads) void collect_scatter_kernel(const DeviceStore st)
+{
+    __shared__ int s_wave_count[kIdxWaves];
+    __shared__ int s_base;
+    const int ch = blockIdx.x;
+    const size_t off = static_cast<size_t>(ch) * st.K;
+
+    // records of all lower channels come first
+    int before = 0;
+    for(int c = threadIdx.x; c < ch; c += kIdxThreads) before += st.dec_count[c];
+    for(int d = 32; d > 0; d >>= 1) before += __shfl_down(before, d);
+    if((threadIdx.x & 63) == 0) s_wave_count[threadIdx.x >> 6] = before;
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+        int total = 0;
+        for(int w = 0; w < kIdxWaves; w++) total += s_wave_count[w];
+        s_base = total;
+        if(ch == st.channels - 1) *st.result_count = total + st.dec_count[ch];
+    }
+    __syncthreads();
+    int base = s_base;
+    __syncthreads();
+
+    msk144_result* __restrict__ out = static_cast<msk144_result*>(st.results);
+    const int per_freq = st.D * kSlotsPerPattern;
+    for(int k0 = 0; k0 < st.K; k0 += kIdxThreads)
+    {
+        const int k = k0 + threadIdx.x;
+        const bool flag = (k < st.K) && st.dec_flag[off + k];
+        const int slot = ordered_slot(flag, base, s_wave_count);
+        if(slot >= 0 && slot < st.max_results)
+        {
+            const int b = k / per_freq;
+            const int p = (k - b * per_freq) / kSlotsPerPattern;
+            msk144_result r;
+            r.channel = ch;
+            r.item = k;
+            r.f0 = st.freq[b];
+            r.pattern_idx = p;
+            r.num_avg = kPatternNumAvg[p];
+            r.pos = st.pos[off + k];
+            r.xb = st.xb[off + k];
+            r.nbadsync = st.nbadsync[off + k];
+            r.ldpc_iterations = st.dec_iter[off + k];
+            r.ldpc_hard_errors = st.dec_nhard[off + k];
+            const uint32_t* w = st.dec_msg + (off + k) * 3;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            r.message[0] = w0 >> 24; r.message[1] = w0 >> 16; r.message[2] = w0 >> 8; r.message[3] = w0;
+            r.message[4] = w1 >> 24; r.message[5] = w1 >> 16; r.message[6] = w1 >> 8; r.message[7] = w1;
+            r.message[8] = w2 >> 24; r.message[9] = w2 >> 16;
+            r.reserved[0] = 0;
+            r.reserved[1] = 0;
+            out[slot] = r;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_index(const DeviceStore& st, hipStream_t stream)
+{
+    hipLaunchKernelGGL(index_kernel, dim3(st.channels), dim3(kIdxThreads), 0, stream, st);
+}
+
+void launch_collect(const DeviceStore& st, hipStream_t stream)
+{
+    hipLaunchKernelGGL(collect_count_kernel, dim3(st.channels), dim3(kIdxThreads), 0, stream, st);
+    hipLaunchKernelGGL(collect_scatter_kernel, dim3(st.channels), dim3(kIdxThreads), 0, stream, st);
+}
+
+}  // namespace msk144

@@ -1,0 +1,250 @@
+// ldpc_bp: log-domain belief propagation for the (128,90) code + CRC-13 + hard-error gate.
+//
+// Replaces ldpc_kernel (ldpc_kernel.cuh:9-249).  The reference runs one 128-thread
+// block per gated candidate; here ONE 64-lane wave decodes one codeword (2 bits, 6 edges per lane):
+//   * hard decisions live in two 64-bit ballot masks (SGPRs); the 38 parity checks are
+//     popcount(cw & H_row) on lanes 0..37, the hard-error count is a popcount of a ballot -
+//     no 11x38 byte scatter, no block reductions, no barriers;
+//   * tanh(-toc/2) is evaluated once per edge (384 per iteration, the reference recomputes 3840) and
+//     parked in a per-wave LDS tile T[slot][check]; each edge then multiplies its check's other slots
+//     in ascending slot order starting from 1.0f - the reference's order, so products are
+//     bit-compatible with ldpc_kernel.cuh:232-246;
+//   * CRC-13 runs as a wave-uniform bit-serial division only when all 38 checks are satisfied;
+//   * the 10th message update of the reference (whose result is never used) is skipped.
+// Work distribution: grid = (blocks per channel, channels); waves stride over the channel's index list
+// (idx/n_idx from index_kernel), so no host read of N_idx sits between the kernels
+// (the reference dereferences a device pointer on the host here, result_keeper.cuh:162).
+#include "msk144_kernels.h"
+#include "wave64.h"
+
+namespace msk144
+{
+
+namespace
+{
+
+constexpr int kLdpcThreads = 256;
+constexpr int kLdpcWaves = kLdpcThreads / 64;
+constexpr int kTStride = 40;  // T[slot][check] row stride (38 checks padded)
+
+// Edge tables derived at compile time from the check-major graph.
+struct EdgeTables
+{
+    int8_t check[kCodeBits][kEdgesPerBit];  // edge k of bit n -> check, k ascending in check
+    int8_t slot[kCodeBits][kEdgesPerBit];   //               -> slot inside that check
+    uint64_t hlo[kChecks];                  // parity-check row as bit masks over cw[0..63], cw[64..127]
+    uint64_t hhi[kChecks];
+    uint8_t full[kChecks];                  // degree-11 checks (ldpc_context.cuh:160-163)
+};
+
+constexpr EdgeTables make_edge_tables()
+{
+    EdgeTables t{};
+    int cnt[kCodeBits] = {};
+    for(int c = 0; c < kChecks; c++)
+    {
+        t.hlo[c] = 0;
+        t.hhi[c] = 0;
+        t.full[c] = kCheckBits[c][kMaxCheckDegree - 1] >= 0 ? 1 : 0;
+        for(int j = 0; j < kMaxCheckDegree; j++)
+        {
+            const int n = kCheckBits[c][j];
+            if(n < 0) continue;
+            t.check[n][cnt[n]] = static_cast<int8_t>(c);
+            t.slot[n][cnt[n]] = static_cast<int8_t>(j);
+            cnt[n]++;
+            if(n < 64) t.hlo[c] |= (1ull << n);
+            else t.hhi[c] |= (1ull << (n - 64));
+        }
+    }
+    return t;
+}
+
+constexpr EdgeTables kEdges = make_edge_tables();
+
+// ldpc_kernel.cuh:65-93 with the branches turned into selects and a single division
+__device__ __forceinline__ float platanh(float x)
+{
+    const float z = __builtin_fabsf(x);
+    const float isign = (x < 0.0f) ? -1.0f : 1.0f;
+    float num, den;
+    if(z <= 0.664f)
+    {
+        num = x;
+        den = 0.83f;
+    }
+    else if(z <= 0.9217f)
+    {
+        num = isign * (z - 0.4064f);
+        den = 0.322f;
+    }
+    else if(z <= 0.9951f)
+    {
+        num = isign * (z - 0.8378f);
+        den = 0.0524f;
+    }
+    else if(z <= 0.9998f)
+    {
+        num = isign * (z - 0.9914f);
+        den = 0.0012f;
+    }
+    else
+    {
+        num = isign * 7.0f;
+        den = 1.0f;
+    }
+    return f32_div(num, den);
+}
+
+// CRC-13 of the 96-bit block (77 message bits + zeros), bit-serial; equals the table walk of
+// ldpc_kernel.cuh:32-43 with ldpc_context.cuh:185-213's table (polynomial x^13 + 0x15D7).
+__device__ __forceinline__ uint32_t crc13_96(uint64_t m_hi64, uint32_t m_lo32)
+{
+    uint32_t rem = 0;
+    for(int i = 63; i >= 0; i--)
+    {
+        rem = (rem << 1) | static_cast<uint32_t>((m_hi64 >> i) & 1ull);
+        if(rem & 0x2000u) rem ^= (0x2000u | kCrc13Poly);
+    }
+    for(int i = 31; i >= 0; i--)
+    {
+        rem = (rem << 1) | ((m_lo32 >> i) & 1u);
+        if(rem & 0x2000u) rem ^= (0x2000u | kCrc13Poly);
+    }
+    return rem & 0x1FFFu;
+}
+
+__global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st)
+{
+    __shared__ float s_t[kLdpcWaves][kMaxCheckDegree * kTStride];
+
+    const int ch = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_idx = st.n_idx[ch];
+    const size_t off = static_cast<size_t>(ch) * st.K;
+    const int32_t* __restrict__ idx = st.idx + off;
+    float* T = s_t[wave];
+
+    // per-lane graph constants: bits lane and lane+64
+    int e_check[2][kEdgesPerBit], e_slot[2][kEdgesPerBit], e_addr[2][kEdgesPerBit];
+#pragma unroll
+    for(int h = 0; h < 2; h++)
+#pragma unroll
+        for(int k = 0; k < kEdgesPerBit; k++)
+        {
+            e_check[h][k] = kEdges.check[lane + 64 * h][k];
+            e_slot[h][k] = kEdges.slot[lane + 64 * h][k];
+            e_addr[h][k] = e_slot[h][k] * kTStride + e_check[h][k];
+        }
+    const int my_check = lane < kChecks ? lane : 0;
+    const uint64_t hlo = kEdges.hlo[my_check];
+    const uint64_t hhi = kEdges.hhi[my_check];
+    bool e_full[2][kEdgesPerBit];
+#pragma unroll
+    for(int h = 0; h < 2; h++)
+#pragma unroll
+        for(int k = 0; k < kEdgesPerBit; k++) e_full[h][k] = kEdges.full[e_check[h][k]] != 0;
+
+    for(int t = lane; t < kMaxCheckDegree * kTStride; t += 64) T[t] = 0.0f;
+
+    for(int i = blockIdx.x * kLdpcWaves + wave; i < n_idx; i += gridDim.x * kLdpcWaves)
+    {
+        const int item = idx[i];
+        const float* __restrict__ L = st.llr + (off + item) * kCodeBits;
+        float llr[2] = {L[lane], L[lane + 64]};
+        float tov[2][kEdgesPerBit] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+
+        for(int iter = 0; iter < kLdpcIterations; iter++)
+        {
+            float zn[2];
+            bool cw[2];
+#pragma unroll
+            for(int h = 0; h < 2; h++)
+            {
+                const float sum = f32_add(f32_add(tov[h][0], tov[h][1]), tov[h][2]);
+                zn[h] = f32_add(llr[h], sum);
+                cw[h] = zn[h] > 0.0f;
+            }
+            const uint64_t lo = __ballot(cw[0]);
+            const uint64_t hi = __ballot(cw[1]);
+
+            // 38 parity checks: lane c < 38 evaluates check c
+            const int par = (__popcll(lo & hlo) + __popcll(hi & hhi)) & 1;
+            const uint64_t syndrome = __ballot(lane < kChecks && par != 0);
+
+            // hard-error count (ldpc_kernel.cuh:203-204)
+            const bool bad0 = cw[0] ? !(llr[0] > 0.0f) : !(llr[0] <= 0.0f);
+            const bool bad1 = cw[1] ? !(llr[1] > 0.0f) : !(llr[1] <= 0.0f);
+            const int nhard = __popcll(__ballot(bad0)) + __popcll(__ballot(bad1));
+
+            if(syndrome == 0)
+            {
+                // codeword MSB first: cw[0] -> bit 63 of m0, cw[64] -> bit 63 of m1
+                const uint64_t m0 = __brevll(lo);
+                const uint64_t m1 = __brevll(hi);
+                const uint32_t crc_rx = static_cast<uint32_t>((m1 >> 38) & 0x1FFFull);        // cw[77..89]
+                const uint32_t tail = static_cast<uint32_t>((m1 & 0xFFF8000000000000ull) >> 32);  // cw[64..76]
+                const uint32_t crc = crc13_96(m0, tail);
+                if(crc == crc_rx && nhard < kMaxHardErrors)
+                {
+                    if(lane == 0)
+                    {
+                        st.dec_flag[off + item] = 1;
+                        st.dec_iter[off + item] = static_cast<uint8_t>(iter);
+                        st.dec_nhard[off + item] = static_cast<uint8_t>(nhard);
+                        uint32_t* w = st.dec_msg + (off + item) * 3;
+                        w[0] = static_cast<uint32_t>(m0 >> 32);
+                        w[1] = static_cast<uint32_t>(m0);
+                        w[2] = tail;
+                    }
+                    break;
+                }
+            }
+            if(iter == kLdpcIterations - 1) break;  // the reference's last update is never consumed
+
+            // bit -> check messages, tanh once per edge (ldpc_kernel.cuh:225-241)
+#pragma unroll
+            for(int h = 0; h < 2; h++)
+#pragma unroll
+                for(int k = 0; k < kEdgesPerBit; k++)
+                {
+                    const float toc = f32_sub(zn[h], tov[h][k]);
+                    T[e_addr[h][k]] = tanhf(-0.5f * toc);
+                }
+            __builtin_amdgcn_wave_barrier();
+
+            // check -> bit messages: leave-one-out product in ascending slot order
+#pragma unroll
+            for(int h = 0; h < 2; h++)
+#pragma unroll
+                for(int k = 0; k < kEdgesPerBit; k++)
+                {
+                    float product = 1.0f;
+#pragma unroll
+                    for(int j = 0; j < kMaxCheckDegree; j++)
+                    {
+                        const float v = T[j * kTStride + e_check[h][k]];
+                        const bool use = (j != e_slot[h][k]) && (j < kMaxCheckDegree - 1 || e_full[h][k]);
+                        product = use ? f32_mul(product, v) : product;
+                    }
+                    tov[h][k] = f32_mul(2.0f, platanh(-product));
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+}  // namespace
+
+void launch_ldpc(const DeviceStore& st, hipStream_t stream)
+{
+    // enough waves to fill 256 CUs x 8 waves/SIMD x 4 SIMDs even for one channel
+    const int max_waves_per_channel = (st.K + kLdpcWaves - 1) / kLdpcWaves;
+    int blocks = (8192 + st.channels - 1) / st.channels;
+    if(blocks > max_waves_per_channel) blocks = max_waves_per_channel;
+    if(blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ldpc_kernel, dim3(blocks, st.channels), dim3(kLdpcThreads), 0, stream, st);
+}
+
+}  // namespace msk144

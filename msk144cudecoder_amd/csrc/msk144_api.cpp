@@ -1,0 +1,672 @@
+// C ABI of libmsk144hip.so (include/msk144hip.h): handle lifetime, buffers, launch order.
+// Host-side restatement of the reference's setup code; compiled with -ffp-contract=off so that the
+// frequency grid, the sync template and the FFT mask are computed with the reference's float ops.
+#include "../../include/msk144hip.h"
+
+#include "msk144_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace msk144;
+
+static_assert(sizeof(msk144_candidate) == kReferenceResultItemBytes, "msk144_candidate must mirror the reference ResultItem");
+static_assert(sizeof(msk144_result) == 52, "msk144_result layout");
+
+struct msk144_handle
+{
+    msk144_params params{};
+    DeviceStore st{};
+    SyncTemplate tpl{};
+    std::vector<float> freq_host;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // device allocations
+    float* d_freq = nullptr;
+    void* d_input = nullptr;  // staging for host-submitted windows
+    float2* d_twiddle = nullptr;
+    float* d_fft_mask = nullptr;
+    std::vector<void*> allocs;
+
+    bool have_window = false;
+    bool decoded = false;
+    bool profiling = false;
+    // HIP-event pairs recorded around each stage; a pool so that many steps can be in flight
+    // before the times are harvested at the next synchronisation point
+    struct Span
+    {
+        int stage;
+        hipEvent_t e0, e1;
+    };
+    std::vector<Span> spans_pending;
+    std::vector<hipEvent_t> ev_free;
+    hipEvent_t ev_open = nullptr;
+    double t_sum[MSK144_T_COUNT]{};
+    int t_cnt[MSK144_T_COUNT]{};
+
+    std::string error;
+};
+
+namespace
+{
+
+thread_local std::string g_create_error;
+
+int fail(msk144_handle* h, int code, const std::string& msg)
+{
+    if(h) h->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                                   \
+    do                                                                                                     \
+    {                                                                                                      \
+        hipError_t e_ = (expr);                                                                            \
+        if(e_ != hipSuccess) return fail(h, MSK144_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while(0)
+
+const float kPiF = 3.14159265358979323846f;
+
+// msk_context.cuh:137-196
+void build_template(SyncTemplate& t)
+{
+    float pp[12];
+    for(int i = 0; i < 12; i++)
+    {
+        float angle = i * kPiF / 12.0f;
+        pp[i] = sinf(angle);
+        t.pp[i] = pp[i];
+    }
+    const int* s8 = kSync8Pm;
+    float cbi[42], cbq[42];
+    for(int i = 0; i < 6; i++) cbq[0 + i] = pp[6 + i] * s8[0];
+    for(int i = 0; i < 12; i++) cbq[6 + i] = pp[i] * s8[2];
+    for(int i = 0; i < 12; i++) cbq[18 + i] = pp[i] * s8[4];
+    for(int i = 0; i < 12; i++) cbq[30 + i] = pp[i] * s8[6];
+    for(int i = 0; i < 12; i++) cbi[0 + i] = pp[i] * s8[1];
+    for(int i = 0; i < 12; i++) cbi[12 + i] = pp[i] * s8[3];
+    for(int i = 0; i < 12; i++) cbi[24 + i] = pp[i] * s8[5];
+    for(int i = 0; i < 6; i++) cbi[36 + i] = pp[i] * s8[7];
+    for(int i = 0; i < 42; i++)
+    {
+        t.re[i] = cbi[i];
+        t.im[i] = cbq[i];
+    }
+}
+
+// analytic_fft.cu:32-57
+void build_fft_mask(std::vector<float>& h)
+{
+    const int nfft = kFftSize;
+    const int nh = nfft / 2;
+    h.assign(nh, 0.0f);
+    const float df = 12000.0f / nfft;
+    const float pi = kPiF;
+    const float t = 1.0f / 2000.0f;
+    const float beta = 0.1f;
+    for(int i = 0; i < nh; i++)
+    {
+        float ff = i * df;
+        float f = ff - 1500.0f;
+        h[i] = 1.0f;
+        if(fabsf(f) > (1 - beta) / (2 * t) && fabsf(f) <= (1 + beta) / (2 * t))
+        {
+            h[i] = h[i] * 0.5f * (1.0f + static_cast<float>(cos((pi * t / beta) * (fabsf(f) - (1 - beta) / (2 * t)))));
+        }
+        else if(fabsf(f) > (1 + beta) / (2 * t))
+        {
+            h[i] = 0;
+        }
+    }
+}
+
+template<typename T>
+int dev_alloc(msk144_handle* h, T** p, size_t count)
+{
+    void* q = nullptr;
+    const size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+    if(e != hipSuccess)
+    {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        return fail(h, MSK144_ENOMEM, buf);
+    }
+    h->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return MSK144_OK;
+}
+
+size_t input_bytes(const msk144_handle* h)
+{
+    const size_t per = (h->params.read_mode == 2) ? 2 * kWindowSamples : kWindowSamples * sizeof(int16_t);
+    return per * h->params.channels;
+}
+
+hipEvent_t ev_take(msk144_handle* h)
+{
+    if(!h->ev_free.empty())
+    {
+        hipEvent_t e = h->ev_free.back();
+        h->ev_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if(hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void ev_begin(msk144_handle* h, int)
+{
+    if(!h->profiling) return;
+    h->ev_open = ev_take(h);
+    if(h->ev_open) hipEventRecord(h->ev_open, h->stream);
+}
+
+void ev_end(msk144_handle* h, int stage)
+{
+    if(!h->profiling || !h->ev_open) return;
+    hipEvent_t e1 = ev_take(h);
+    if(!e1)
+    {
+        h->ev_free.push_back(h->ev_open);
+        h->ev_open = nullptr;
+        return;
+    }
+    hipEventRecord(e1, h->stream);
+    h->spans_pending.push_back({stage, h->ev_open, e1});
+    h->ev_open = nullptr;
+}
+
+// fold finished event pairs into the running sums; requires the stream to be idle
+void harvest_times(msk144_handle* h)
+{
+    for(const auto& sp : h->spans_pending)
+    {
+        float ms = 0.0f;
+        if(hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess)
+        {
+            h->t_sum[sp.stage] += ms;
+            h->t_cnt[sp.stage]++;
+        }
+        h->ev_free.push_back(sp.e0);
+        h->ev_free.push_back(sp.e1);
+    }
+    h->spans_pending.clear();
+}
+
+int run_frontend(msk144_handle* h, const void* d_in)
+{
+    ev_begin(h, MSK144_T_FRONTEND);
+    if(h->params.read_mode == 2) launch_frontend_iq(h->st, static_cast<const int8_t*>(d_in), h->stream);
+    else launch_frontend_audio(h->st, static_cast<const int16_t*>(d_in), h->params.analytic_method, h->d_twiddle, h->d_fft_mask, h->stream);
+    ev_end(h, MSK144_T_FRONTEND);
+    HIP_TRY(h, hipGetLastError());
+    h->have_window = true;
+    h->decoded = false;
+    return MSK144_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void msk144_default_params(msk144_params* p)
+{
+    if(!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->center_hz = 1500.0f;  // main.cu:124 (audio); IQ callers set 0 (main.cu:125)
+    p->width_hz = 200.0f;    // main.cu:130
+    p->step_hz = 2.0f;       // main.cu:129
+    p->scan_depth = 4;       // main.cu:131
+    p->nbadsync_threshold = 1;  // main.cu:133
+    p->read_mode = 1;
+    p->analytic_method = 2;  // main.cu:132
+    p->channels = 1;
+    p->device = 0;
+    p->max_results = 0;
+}
+
+const char* msk144_last_error(const msk144_handle* h)
+{
+    return h ? h->error.c_str() : g_create_error.c_str();
+}
+
+int msk144_create(const msk144_params* params, msk144_handle** out)
+{
+    if(!params || !out) return fail(nullptr, MSK144_EINVAL, "null argument");
+    *out = nullptr;
+    if(!(params->step_hz > 0.0f)) return fail(nullptr, MSK144_EINVAL, "search step must be > 0");  // assert at msk_context.cuh:97
+    if(!(params->width_hz >= 0.0f)) return fail(nullptr, MSK144_EINVAL, "search width must be >= 0");
+    if(params->channels < 1) return fail(nullptr, MSK144_EINVAL, "channels must be >= 1");
+    if(params->read_mode != 1 && params->read_mode != 2) return fail(nullptr, MSK144_EINVAL, "read_mode must be 1 (audio) or 2 (IQ)");
+    if(params->read_mode == 1 && params->analytic_method != 1 && params->analytic_method != 2)
+        return fail(nullptr, MSK144_EINVAL, "analytic_method must be 1 (FFT) or 2 (shift-filter-shift)");
+
+    msk144_handle* h = new(std::nothrow) msk144_handle();
+    if(!h) return fail(nullptr, MSK144_ENOMEM, "out of host memory");
+    h->params = *params;
+    h->params.scan_depth = clamp_scan_depth(params->scan_depth);
+
+    auto bail = [&](int code) {
+        g_create_error = h->error;
+        msk144_destroy(h);
+        return code;
+    };
+
+    int ndev = 0;
+    if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    {
+        h->error = "no HIP device available (libmsk144hip has no CPU fallback)";
+        return bail(MSK144_EHIP);
+    }
+    if(params->device < 0 || params->device >= ndev)
+    {
+        h->error = "device ordinal out of range";
+        return bail(MSK144_EINVAL);
+    }
+    if(hipSetDevice(params->device) != hipSuccess)
+    {
+        h->error = "hipSetDevice failed";
+        return bail(MSK144_EHIP);
+    }
+
+    // frequency grid (msk_context.cuh:95-107,135)
+    const int half_len = grid_half_len(params->width_hz, params->step_hz);
+    const int F = half_len * 2 + 1;
+    const float if1 = -1 * half_len * params->step_hz;
+    h->freq_host.resize(F);
+    for(int b = 0; b < F; b++) h->freq_host[b] = params->center_hz + if1 + static_cast<int>(b) * params->step_hz;
+
+    DeviceStore& st = h->st;
+    st.channels = params->channels;
+    st.F = F;
+    st.D = h->params.scan_depth;
+    st.K = F * st.D * kSlotsPerPattern;
+    st.nbadsync_threshold = params->nbadsync_threshold;
+    const long long total = static_cast<long long>(st.channels) * st.K;
+    long long maxr = params->max_results > 0 ? params->max_results : (1 << 20);
+    if(maxr > total) maxr = total;
+    st.max_results = static_cast<int32_t>(maxr);
+    h->params.max_results = st.max_results;
+
+    build_template(h->tpl);
+
+    if(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        h->error = "hipStreamCreate failed";
+        return bail(MSK144_EHIP);
+    }
+    h->stream = h->own_stream;
+
+    const size_t ck = static_cast<size_t>(total);
+    int rc = MSK144_OK;
+    auto A = [&](int r) { if(rc == MSK144_OK) rc = r; };
+    A(dev_alloc(h, &h->d_freq, F));
+    A(dev_alloc(h, &st.analytic, static_cast<size_t>(st.channels) * kWindowSamples));
+    A(dev_alloc(h, &st.seg_power, static_cast<size_t>(st.channels) * 8));
+    A(dev_alloc(h, &st.pos, ck));
+    A(dev_alloc(h, &st.xb, ck));
+    A(dev_alloc(h, &st.nbadsync, ck));
+    A(dev_alloc(h, &st.llr, ck * kCodeBits));
+    A(dev_alloc(h, &st.idx, ck));
+    A(dev_alloc(h, &st.n_idx, st.channels));
+    A(dev_alloc(h, &st.dec_flag, ck));
+    A(dev_alloc(h, &st.dec_iter, ck));
+    A(dev_alloc(h, &st.dec_nhard, ck));
+    A(dev_alloc(h, &st.dec_msg, ck * 3));
+    A(dev_alloc(h, &st.dec_count, st.channels));
+    A(dev_alloc(h, &st.result_count, 1));
+    {
+        msk144_result* r = nullptr;
+        A(dev_alloc(h, &r, st.max_results));
+        st.results = r;
+    }
+    {
+        uint8_t* in = nullptr;
+        A(dev_alloc(h, &in, input_bytes(h)));
+        h->d_input = in;
+    }
+    if(rc != MSK144_OK) return bail(rc);
+    st.freq = h->d_freq;
+
+    bool ok = hipMemcpy(h->d_freq, h->freq_host.data(), sizeof(float) * F, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(st.dec_flag, 0, ck) == hipSuccess;
+    ok = ok && hipMemset(st.n_idx, 0, sizeof(int32_t) * st.channels) == hipSuccess;
+    ok = ok && hipMemset(st.dec_count, 0, sizeof(int32_t) * st.channels) == hipSuccess;
+    ok = ok && hipMemset(st.result_count, 0, sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMemset(st.pos, 0, ck * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(st.nbadsync, 0, ck * sizeof(int32_t)) == hipSuccess;
+
+    if(ok && params->read_mode == 1 && params->analytic_method == 1)
+    {
+        std::vector<float> mask;
+        build_fft_mask(mask);
+        std::vector<float2> tw(kFftSize / 2);
+        for(int j = 0; j < kFftSize / 2; j++)
+        {
+            const double ang = -2.0 * M_PI * j / kFftSize;
+            tw[j] = make_float2(static_cast<float>(cos(ang)), static_cast<float>(sin(ang)));
+        }
+        if(dev_alloc(h, &h->d_twiddle, tw.size()) != MSK144_OK || dev_alloc(h, &h->d_fft_mask, mask.size()) != MSK144_OK) return bail(MSK144_ENOMEM);
+        ok = ok && hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(h->d_fft_mask, mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if(!ok)
+    {
+        h->error = std::string("device initialisation failed: ") + hipGetErrorString(hipGetLastError());
+        return bail(MSK144_EHIP);
+    }
+    *out = h;
+    return MSK144_OK;
+}
+
+void msk144_destroy(msk144_handle* h)
+{
+    if(!h) return;
+    if(h->stream) hipStreamSynchronize(h->stream);
+    for(void* p : h->allocs) hipFree(p);
+    for(const auto& sp : h->spans_pending)
+    {
+        hipEventDestroy(sp.e0);
+        hipEventDestroy(sp.e1);
+    }
+    for(hipEvent_t e : h->ev_free) hipEventDestroy(e);
+    if(h->ev_open) hipEventDestroy(h->ev_open);
+    if(h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int msk144_geometry(const msk144_handle* h, int32_t* num_freqs, int32_t* scan_depth, int32_t* items_per_channel)
+{
+    if(!h) return MSK144_EINVAL;
+    if(num_freqs) *num_freqs = h->st.F;
+    if(scan_depth) *scan_depth = h->st.D;
+    if(items_per_channel) *items_per_channel = h->st.K;
+    return MSK144_OK;
+}
+
+int msk144_frequency(const msk144_handle* h, int32_t block_idx, float* hz)
+{
+    if(!h || !hz || block_idx < 0 || block_idx >= h->st.F) return MSK144_EINVAL;
+    *hz = h->freq_host[block_idx];
+    return MSK144_OK;
+}
+
+int msk144_set_stream(msk144_handle* h, void* hip_stream)
+{
+    if(!h) return MSK144_EINVAL;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    harvest_times(h);
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return MSK144_OK;
+}
+
+int msk144_submit_audio(msk144_handle* h, const int16_t* windows)
+{
+    if(!h || !windows) return fail(h, MSK144_EINVAL, "null argument");
+    if(h->params.read_mode != 1) return fail(h, MSK144_ESTATE, "handle was created for IQ input (read_mode 2)");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_input, windows, input_bytes(h), hipMemcpyHostToDevice, h->stream));
+    return run_frontend(h, h->d_input);
+}
+
+int msk144_submit_iq(msk144_handle* h, const int8_t* windows)
+{
+    if(!h || !windows) return fail(h, MSK144_EINVAL, "null argument");
+    if(h->params.read_mode != 2) return fail(h, MSK144_ESTATE, "handle was created for audio input (read_mode 1)");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_input, windows, input_bytes(h), hipMemcpyHostToDevice, h->stream));
+    return run_frontend(h, h->d_input);
+}
+
+int msk144_submit_audio_device(msk144_handle* h, const int16_t* d_windows)
+{
+    if(!h || !d_windows) return fail(h, MSK144_EINVAL, "null argument");
+    if(h->params.read_mode != 1) return fail(h, MSK144_ESTATE, "handle was created for IQ input (read_mode 2)");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    return run_frontend(h, d_windows);
+}
+
+int msk144_submit_iq_device(msk144_handle* h, const int8_t* d_windows)
+{
+    if(!h || !d_windows) return fail(h, MSK144_EINVAL, "null argument");
+    if(h->params.read_mode != 2) return fail(h, MSK144_ESTATE, "handle was created for audio input (read_mode 1)");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    return run_frontend(h, d_windows);
+}
+
+int msk144_submit_analytic(msk144_handle* h, const float* windows)
+{
+    if(!h || !windows) return fail(h, MSK144_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    HIP_TRY(h, hipMemcpyAsync(h->st.analytic, windows, sizeof(float2) * kWindowSamples * h->st.channels, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_window = true;
+    h->decoded = false;
+    return MSK144_OK;
+}
+
+int msk144_decode_stages(msk144_handle* h, uint32_t stages)
+{
+    if(!h) return MSK144_EINVAL;
+    if((stages & (MSK144_STAGE_SCAN | MSK144_STAGE_SOFTBITS)) && !h->have_window) return fail(h, MSK144_ESTATE, "decode before any window was submitted");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    if(stages & MSK144_STAGE_SCAN)
+    {
+        ev_begin(h, MSK144_T_SCAN);
+        launch_scan(h->st, h->tpl, h->stream);
+        ev_end(h, MSK144_T_SCAN);
+    }
+    if(stages & MSK144_STAGE_SOFTBITS)
+    {
+        ev_begin(h, MSK144_T_SOFTBITS);
+        launch_softbits(h->st, h->tpl, h->stream);
+        ev_end(h, MSK144_T_SOFTBITS);
+    }
+    if(stages & MSK144_STAGE_INDEX)
+    {
+        ev_begin(h, MSK144_T_INDEX);
+        launch_index(h->st, h->stream);
+        ev_end(h, MSK144_T_INDEX);
+    }
+    if(stages & MSK144_STAGE_LDPC)
+    {
+        ev_begin(h, MSK144_T_LDPC);
+        launch_ldpc(h->st, h->stream);
+        ev_end(h, MSK144_T_LDPC);
+    }
+    if(stages & MSK144_STAGE_COLLECT)
+    {
+        ev_begin(h, MSK144_T_COLLECT);
+        launch_collect(h->st, h->stream);
+        ev_end(h, MSK144_T_COLLECT);
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->decoded = true;
+    return MSK144_OK;
+}
+
+int msk144_decode(msk144_handle* h)
+{
+    return msk144_decode_stages(h, MSK144_STAGE_ALL);
+}
+
+int msk144_synchronize(msk144_handle* h)
+{
+    if(!h) return MSK144_EINVAL;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    harvest_times(h);
+    return MSK144_OK;
+}
+
+int msk144_result_count(msk144_handle* h, int32_t* n)
+{
+    if(!h || !n) return fail(h, MSK144_EINVAL, "null argument");
+    if(!h->decoded) return fail(h, MSK144_ESTATE, "no decode has been run");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    HIP_TRY(h, hipMemcpy(n, h->st.result_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MSK144_OK;
+}
+
+int msk144_results(msk144_handle* h, msk144_result* out, int32_t cap, int32_t* n)
+{
+    if(!h || !n || (cap > 0 && !out)) return fail(h, MSK144_EINVAL, "null argument");
+    int32_t total = 0;
+    int rc = msk144_result_count(h, &total);
+    if(rc != MSK144_OK) return rc;
+    *n = total;
+    int32_t avail = total < h->st.max_results ? total : h->st.max_results;
+    int32_t ncopy = avail < cap ? avail : cap;
+    if(ncopy > 0) HIP_TRY(h, hipMemcpy(out, h->st.results, sizeof(msk144_result) * ncopy, hipMemcpyDeviceToHost));
+    if(total > h->st.max_results) return fail(h, MSK144_EOVERFLOW, "more decodes than max_results; list truncated");
+    return MSK144_OK;
+}
+
+int msk144_results_device(msk144_handle* h, const msk144_result** d_records, const int32_t** d_count)
+{
+    if(!h || !d_records || !d_count) return fail(h, MSK144_EINVAL, "null argument");
+    *d_records = static_cast<const msk144_result*>(h->st.results);
+    *d_count = h->st.result_count;
+    return MSK144_OK;
+}
+
+int msk144_segment_power(msk144_handle* h, float* out)
+{
+    if(!h || !out) return fail(h, MSK144_EINVAL, "null argument");
+    if(!h->have_window) return fail(h, MSK144_ESTATE, "no window submitted");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    HIP_TRY(h, hipMemcpy(out, h->st.seg_power, sizeof(float) * 8 * h->st.channels, hipMemcpyDeviceToHost));
+    return MSK144_OK;
+}
+
+int msk144_dump_analytic(msk144_handle* h, int32_t channel, float* out)
+{
+    if(!h || !out || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    HIP_TRY(h, hipMemcpy(out, h->st.analytic + static_cast<size_t>(channel) * kWindowSamples, sizeof(float2) * kWindowSamples, hipMemcpyDeviceToHost));
+    return MSK144_OK;
+}
+
+int msk144_dump_candidates(msk144_handle* h, int32_t channel, msk144_candidate* out)
+{
+    if(!h || !out || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    const DeviceStore& st = h->st;
+    const size_t K = st.K;
+    const size_t off = static_cast<size_t>(channel) * K;
+    std::vector<uint32_t> pos(K), msg(K * 3);
+    std::vector<float> xb(K), llr(K * kCodeBits);
+    std::vector<int32_t> nbad(K);
+    std::vector<uint8_t> flag(K), iter(K), nhard(K);
+    HIP_TRY(h, hipMemcpy(pos.data(), st.pos + off, K * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(xb.data(), st.xb + off, K * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(nbad.data(), st.nbadsync + off, K * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(llr.data(), st.llr + off * kCodeBits, K * kCodeBits * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(flag.data(), st.dec_flag + off, K, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(iter.data(), st.dec_iter + off, K, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(nhard.data(), st.dec_nhard + off, K, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(msg.data(), st.dec_msg + off * 3, K * 12, hipMemcpyDeviceToHost));
+    const int per_freq = st.D * kSlotsPerPattern;
+    std::memset(out, 0, sizeof(msk144_candidate) * K);
+    for(size_t k = 0; k < K; k++)
+    {
+        msk144_candidate& c = out[k];
+        const int b = static_cast<int>(k) / per_freq;
+        const int p = (static_cast<int>(k) - b * per_freq) / kSlotsPerPattern;
+        c.block_idx = b;
+        c.pattern_idx = p;
+        c.pos = pos[k];
+        c.f0 = h->freq_host[b];
+        c.nbadsync = nbad[k];
+        c.xb = xb[k];
+        c.num_avg = kPatternNumAvg[p];
+        std::memcpy(c.softbits_wo_sync, &llr[k * kCodeBits], sizeof(float) * kCodeBits);
+        if(flag[k])
+        {
+            c.is_message_present = 1;
+            c.ldpc_num_iterations = iter[k];
+            c.ldpc_num_hard_errors = nhard[k];
+            for(int i = 0; i < kMessageBits; i++) c.message[i] = static_cast<char>((msg[k * 3 + i / 32] >> (31 - (i % 32))) & 1u);
+        }
+    }
+    return MSK144_OK;
+}
+
+int msk144_dump_indexes(msk144_handle* h, int32_t channel, int32_t* out, int32_t* n)
+{
+    if(!h || !out || !n || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    HIP_TRY(h, hipMemcpy(n, h->st.n_idx + channel, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if(*n > 0) HIP_TRY(h, hipMemcpy(out, h->st.idx + static_cast<size_t>(channel) * h->st.K, sizeof(int32_t) * (*n), hipMemcpyDeviceToHost));
+    return MSK144_OK;
+}
+
+int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candidate* items)
+{
+    if(!h || !items || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    const DeviceStore& st = h->st;
+    const size_t K = st.K;
+    const size_t off = static_cast<size_t>(channel) * K;
+    std::vector<uint32_t> pos(K);
+    std::vector<float> xb(K), llr(K * kCodeBits);
+    std::vector<int32_t> nbad(K);
+    for(size_t k = 0; k < K; k++)
+    {
+        pos[k] = items[k].pos;
+        xb[k] = items[k].xb;
+        nbad[k] = items[k].nbadsync;
+        std::memcpy(&llr[k * kCodeBits], items[k].softbits_wo_sync, sizeof(float) * kCodeBits);
+    }
+    HIP_TRY(h, hipMemcpy(st.pos + off, pos.data(), K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(st.xb + off, xb.data(), K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(st.nbadsync + off, nbad.data(), K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(st.llr + off * kCodeBits, llr.data(), K * kCodeBits * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemset(st.dec_flag + off, 0, K));
+    return MSK144_OK;
+}
+
+int msk144_set_profiling(msk144_handle* h, int32_t enable)
+{
+    if(!h) return MSK144_EINVAL;
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    h->profiling = enable != 0;
+    return MSK144_OK;
+}
+
+int msk144_stage_times(msk144_handle* h, float* avg_ms, int32_t* samples, int32_t reset)
+{
+    if(!h || !avg_ms) return fail(h, MSK144_EINVAL, "null argument");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    for(int s = 0; s < MSK144_T_COUNT; s++) avg_ms[s] = h->t_cnt[s] ? static_cast<float>(h->t_sum[s] / h->t_cnt[s]) : 0.0f;
+    if(samples)
+        for(int s = 0; s < MSK144_T_COUNT; s++) samples[s] = h->t_cnt[s];
+    if(reset)
+    {
+        for(int s = 0; s < MSK144_T_COUNT; s++)
+        {
+            h->t_sum[s] = 0.0;
+            h->t_cnt[s] = 0;
+        }
+    }
+    return MSK144_OK;
+}
+
+}  // extern "C"

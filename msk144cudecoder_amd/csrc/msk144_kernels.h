@@ -1,0 +1,65 @@
+// Internal interface between the C-ABI host code (msk144_api.cpp) and the gfx950 kernels.
+// One launcher per reference kernel; every launcher only enqueues work on `stream`.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msk144_protocol.h"
+
+namespace msk144
+{
+
+// 42-tap sync template and the 12-sample half-sine, built on the host exactly like
+// msk_context.cuh:137-196 and handed to kernels by value (kernarg -> SGPRs).
+struct SyncTemplate
+{
+    float re[kSyncTaps];
+    float im[kSyncTaps];
+    float pp[12];
+};
+
+// Candidate store, structure-of-arrays, [channel][item] with item k = b*D*8 + p*8 + slot
+// (result_keeper.cuh:85-91).  Replaces the reference's 632-byte array-of-structs ResultItem.
+struct DeviceStore
+{
+    int32_t channels;
+    int32_t F;                // frequency hypotheses
+    int32_t D;                // scan depth (patterns)
+    int32_t K;                // items per channel = F*D*8
+    int32_t nbadsync_threshold;
+    int32_t max_results;
+
+    const float* freq;        // [F] Hz, host-computed as msk_context.cuh:135
+    float2* analytic;         // [channels][5184] front-end output
+    float* seg_power;         // [channels][8]
+
+    uint32_t* pos;            // [channels][K]
+    float* xb;                // [channels][K]
+    int32_t* nbadsync;        // [channels][K]
+    float* llr;               // [channels][K][128]
+    int32_t* idx;             // [channels][K] gated item numbers, ascending
+    int32_t* n_idx;           // [channels]
+    uint8_t* dec_flag;        // [channels][K] is_message_present
+    uint8_t* dec_iter;        // [channels][K]
+    uint8_t* dec_nhard;       // [channels][K]
+    uint32_t* dec_msg;        // [channels][K][3]  77 bits MSB first in 96
+
+    int32_t* dec_count;       // [channels] decodes per channel
+    int32_t* result_count;    // [1]
+    void* results;            // [max_results] msk144_result
+};
+
+// front ends (frontend.hip)
+void launch_frontend_audio(const DeviceStore& st, const int16_t* d_in, int analytic_method, const float2* d_twiddle, const float* d_fft_mask,
+                           hipStream_t stream);
+void launch_frontend_iq(const DeviceStore& st, const int8_t* d_in, hipStream_t stream);
+
+// hot kernels
+void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t stream);
+void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t stream);
+void launch_index(const DeviceStore& st, hipStream_t stream);
+void launch_ldpc(const DeviceStore& st, hipStream_t stream);
+void launch_collect(const DeviceStore& st, hipStream_t stream);
+
+}  // namespace msk144
