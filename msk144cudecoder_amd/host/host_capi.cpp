@@ -1,0 +1,72 @@
+// C entry points of the GPU-independent host logic, for the CPU test-suite (libmsk144host.so).
+#include "window_decoder.h"
+
+#include <cstring>
+
+using namespace msk144host;
+
+extern "C" {
+
+void* msk144host_table_new() { return new CallHashTable(); }
+void msk144host_table_free(void* t) { delete static_cast<CallHashTable*>(t); }
+void msk144host_table_clear(void* t) { static_cast<CallHashTable*>(t)->clear(); }
+unsigned msk144host_hash(const char* call, int bits) { return CallHashTable::hash(call, bits); }
+
+int msk144host_message_gate(const unsigned char* bits77) { return message_gate(bits77) ? 1 : 0; }
+
+// out: at least 64 bytes
+int msk144host_decode_message(void* table, const unsigned char* bits77, char* out)
+{
+    std::string text;
+    const bool ok = decode_message(bits77, *static_cast<CallHashTable*>(table), text);
+    std::strncpy(out, text.c_str(), 63);
+    out[63] = 0;
+    return ok ? 1 : 0;
+}
+
+void* msk144host_snr_new() { return new SnrTracker(); }
+void msk144host_snr_free(void* s) { delete static_cast<SnrTracker*>(s); }
+int msk144host_snr_update(void* s, const float* seg8)
+{
+    static_cast<SnrTracker*>(s)->update(seg8);
+    return static_cast<SnrTracker*>(s)->snr_int();
+}
+float msk144host_snr_db(void* s) { return static_cast<SnrTracker*>(s)->snr_db(); }
+
+// Post-process one window.  accepted: n records of {f0, num_avg, nbadsync, pattern_idx, bits[77]} in
+// item order.  Lines are written as a '\n'-joined string of format_line() outputs with the date field
+// blanked (tests mask it anyway).  Returns the number of lines.
+struct msk144host_accepted
+{
+    float f0;
+    int num_avg;
+    int nbadsync;
+    int pattern_idx;
+    unsigned char bits[77];
+};
+
+int msk144host_postprocess(void* table, const msk144host_accepted* acc, int n, int snr, int quirk, char* out, int out_cap)
+{
+    std::vector<AcceptedCandidate> v(n);
+    for(int i = 0; i < n; i++)
+    {
+        v[i].f0 = acc[i].f0;
+        v[i].num_avg = acc[i].num_avg;
+        v[i].nbadsync = acc[i].nbadsync;
+        v[i].pattern_idx = acc[i].pattern_idx;
+        std::memcpy(v[i].bits, acc[i].bits, 77);
+    }
+    ResultFilter filter;
+    std::vector<FilteredResult> lines = postprocess_window(v, snr, quirk != 0, *static_cast<CallHashTable*>(table), filter);
+    std::string joined;
+    for(size_t i = 0; i < lines.size(); i++)
+    {
+        if(i) joined += "\n";
+        joined += lines[i].format_line();
+    }
+    std::strncpy(out, joined.c_str(), out_cap - 1);
+    out[out_cap - 1] = 0;
+    return static_cast<int>(lines.size());
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// One input stream on top of the C ABI: the host part of the reference's working loop
+// (main.cu:388-419) and of do_decode (main.cu:474-525) - SNR tracking, payload -> text with the
+// per-window decode cache, per-window result filter.
+#pragma once
+
+#include "../../include/msk144hip.h"
+#include "result_filter.h"
+#include "snr_tracker.h"
+#include "unpack77.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace msk144host
+{
+
+struct DecoderOptions
+{
+    float center_hz = 1500.0f;
+    float width_hz = 200.0f;
+    float step_hz = 2.0f;
+    int scan_depth = 4;
+    int nbadsync_threshold = 1;
+    int read_mode = 1;
+    int analytic_method = 2;
+    int device = 0;
+    // The reference keys its per-window decode cache with a comparator that is always false
+    // (main.cu:437-445), so every accepted candidate of a window receives the text - or the unpack
+    // failure - of the FIRST accepted candidate.  true (default) reproduces that; false unpacks every
+    // distinct payload (--strict-decode).
+    bool reference_cache_quirk = true;
+    bool print_bits = false;  // append the 77-bit payload to each line (debug)
+};
+
+// What one accepted candidate contributes, independent of the GPU (unit-testable on the CPU).
+struct AcceptedCandidate
+{
+    float f0;
+    int num_avg;
+    int nbadsync;
+    int pattern_idx;
+    uint8_t bits[77];
+};
+
+// Host post-processing of one window given the accepted candidates in item order.
+std::vector<FilteredResult> postprocess_window(const std::vector<AcceptedCandidate>& accepted, int snr, bool reference_cache_quirk, CallHashTable& table,
+                                               ResultFilter& filter);
+
+void unpack_bits(const uint8_t packed[10], uint8_t bits[77]);
+
+class WindowDecoder
+{
+public:
+    explicit WindowDecoder(const DecoderOptions& opt);
+    ~WindowDecoder();
+    WindowDecoder(const WindowDecoder&) = delete;
+    WindowDecoder& operator=(const WindowDecoder&) = delete;
+
+    bool ok() const { return handle_ != nullptr; }
+    const std::string& error() const { return error_; }
+
+    int num_freqs() const { return F_; }
+    int scan_depth() const { return D_; }
+    float left_bound() const;
+    float right_bound() const;
+
+    // one 5184-sample window (int16 audio or interleaved int8 I/Q); returns false on a library error
+    bool process(const void* window, std::vector<FilteredResult>& lines);
+
+private:
+    DecoderOptions opt_;
+    msk144_handle* handle_ = nullptr;
+    int F_ = 0, D_ = 0, K_ = 0;
+    std::string error_;
+    SnrTracker snr_;
+    ResultFilter filter_;
+    CallHashTable calls_;
+    std::vector<msk144_result> results_;
+};
+
+}  // namespace msk144host

@@ -1,0 +1,92 @@
+"""-m gpu: the stdin -> stdout program (msk144hipdecoder) against lines predicted from the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from msk144cudecoder_amd import synth
+
+from test_host import Accepted
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "msk144cudecoder_amd", "msk144hipdecoder")
+HOST_SO = os.path.join(ROOT, "msk144cudecoder_amd", "libmsk144host.so")
+
+
+def _expected_lines(orc, stream, cfg, read_mode, quirk):
+    """Oracle decode of every window + the host library's post-processing (the same C++ the CLI links)."""
+    H = C.CDLL(HOST_SO)
+    H.msk144host_table_new.restype = C.c_void_p
+    H.msk144host_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    table = H.msk144host_table_new()
+    o = orc.Oracle(threads=8, **cfg)
+    snr = orc.Snr()
+    out = []
+    for w in synth.windows_of(stream, read_mode):
+        cd = o.frontend_audio(w, 2) if read_mode == 1 else o.frontend_iq(w)
+        s = snr.process(cd)
+        items, _ = o.decode_window(cd)
+        acc = items[items["is_message_present"] == 1]
+        arr = (Accepted * max(len(acc), 1))()
+        for a, it in zip(arr, acc):
+            a.f0, a.num_avg, a.nbadsync, a.pattern_idx = float(it["f0"]), int(it["num_avg"]), int(it["nbadsync"]), int(it["pattern_idx"])
+            a.bits[:] = [int(b) for b in it["message"]]
+        buf = C.create_string_buffer(16384)
+        n = H.msk144host_postprocess(table, arr, len(acc), s, 1 if quirk else 0, buf, len(buf))
+        if n:
+            out += buf.value.decode().split("\n")
+    return [re.sub(r"date=\d{14}", "date=X", l) for l in out]
+
+
+def _run(args, data):
+    p = subprocess.run([EXE] + args, input=data, capture_output=True, timeout=300)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_cli_audio_stream(orc):
+    rng = np.random.default_rng(77)
+    n = 5184 + 4 * 2592
+    msgs = [synth.random_message(rng) for _ in range(2)]
+    pings = [synth.Ping(msgs[0], 1500, 6, 1503.0, 4.0, 0.4), synth.Ping(msgs[1], 9000, 5, 1495.0, 5.0, 1.4)]
+    stream = synth.synth_audio(n, pings, 1000.0, rng)
+    cfg = dict(center=1500.0, width=20.0, step=1.0, depth=6, nbadsync_threshold=2)
+    args = ["--search-width=20", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=2"]
+    rc, out, err = _run(args + ["--strict-decode"], stream.tobytes())
+    assert rc == 0, err
+    lines = out.strip().split("\n")
+    assert lines[-1] == "Done"
+    got = [re.sub(r"date=\d{14}", "date=X", l) for l in lines[:-1]]
+    assert "Actual parameters:" in err and "Incomplete read error. rc=0" in err
+    want = _expected_lines(orc, stream, cfg, 1, quirk=False)
+    assert len(want) >= 2
+    assert got == want
+    # every line has the reference's field layout (main.cu:409-417)
+    pat = re.compile(r"^\*\*\*  snr=[ -]?\d+; f0=\s*[\d.]+; num_avg=\d; nbadsync=\d+; pattern_idx=\d; date=X; msg='.*'; $")
+    assert all(pat.match(l) for l in got)
+    # default mode reproduces the reference's first-candidate cache behaviour
+    rc, out2, _ = _run(args, stream.tobytes())
+    got2 = [re.sub(r"date=\d{14}", "date=X", l) for l in out2.strip().split("\n")[:-1]]
+    assert got2 == _expected_lines(orc, stream, cfg, 1, quirk=True)
+
+
+def test_cli_iq_and_option_quirks(orc):
+    rng = np.random.default_rng(78)
+    msg = synth.random_message(rng)
+    stream = synth.synth_iq(5184 + 2592, [synth.Ping(msg, 800, 6, 2.0, 4.0, 0.1)], 20.0, rng)
+    cfg = dict(center=0.0, width=12.0, step=2.0, depth=4, nbadsync_threshold=1)
+    rc, out, err = _run(["--read-mode=2", "--search-width=12", "--strict-decode"], stream.tobytes())
+    assert rc == 0 and out.strip().endswith("Done")
+    got = [re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]]
+    assert got == _expected_lines(orc, stream, cfg, 2, quirk=False) and len(got) >= 1
+    # short input: error on stderr, Done on stdout, exit 0 (main.cu:274-278,424)
+    rc, out, err = _run([], b"\x00" * 100)
+    assert rc == 0 and out.strip() == "Done" and "Incomplete read error. rc=50" in err
+    # bad read mode without a centre frequency -> exit 2 (main.cu:193-207)
+    rc, out, err = _run(["--read-mode=5"], b"")
+    assert rc == 2 and "Wrong read mode 5" in err
+    rc, out, _ = _run(["--help"], b"")
+    assert rc == 0 and "--nbadsync-threshold" in out

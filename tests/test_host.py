@@ -1,0 +1,170 @@
+"""GPU-independent host logic (next rows f-1/f-2): text layer, SNR tracker, per-window result filter
+and the reference's decode-cache quirk, through libmsk144host.so (plain C entry points)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import pack77
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "msk144cudecoder_amd", "host")
+SO = os.path.join(ROOT, "msk144cudecoder_amd", "libmsk144host.so")
+
+
+class Accepted(C.Structure):
+    _fields_ = [("f0", C.c_float), ("num_avg", C.c_int), ("nbadsync", C.c_int), ("pattern_idx", C.c_int), ("bits", C.c_ubyte * 77)]
+
+
+@pytest.fixture(scope="module")
+def H():
+    subprocess.run(["make", "-s", "-C", HOST_DIR, SO.replace(ROOT + "/msk144cudecoder_amd", "..")], check=True)
+    L = C.CDLL(SO)
+    L.msk144host_table_new.restype = C.c_void_p
+    L.msk144host_table_free.argtypes = [C.c_void_p]
+    L.msk144host_table_clear.argtypes = [C.c_void_p]
+    L.msk144host_hash.argtypes = [C.c_char_p, C.c_int]
+    L.msk144host_hash.restype = C.c_uint
+    L.msk144host_message_gate.argtypes = [C.c_void_p]
+    L.msk144host_decode_message.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    L.msk144host_snr_new.restype = C.c_void_p
+    L.msk144host_snr_free.argtypes = [C.c_void_p]
+    L.msk144host_snr_update.argtypes = [C.c_void_p, C.c_void_p]
+    L.msk144host_snr_db.argtypes = [C.c_void_p]
+    L.msk144host_snr_db.restype = C.c_float
+    L.msk144host_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    return L
+
+
+def _decode(H, table, bits):
+    b = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = C.create_string_buffer(64)
+    ok = H.msk144host_decode_message(table, b.ctypes.data_as(C.c_void_p), out)
+    return bool(ok), out.value.decode()
+
+
+def test_standard_messages(H):
+    t = H.msk144host_table_new()
+    cases = [
+        ("CQ", "K1ABC", "FN42", "CQ K1ABC FN42"),
+        ("K1ABC", "W9XYZ", "EN37", "K1ABC W9XYZ EN37"),
+        ("W9XYZ", "K1ABC", "-11", "W9XYZ K1ABC -11"),
+        ("K1ABC", "W9XYZ", "R-09", "K1ABC W9XYZ R-09"),
+        ("W9XYZ", "K1ABC", "RRR", "W9XYZ K1ABC RRR"),
+        ("K1ABC", "W9XYZ", "RR73", "K1ABC W9XYZ RR73"),
+        ("K1ABC", "W9XYZ", "73", "K1ABC W9XYZ 73"),
+        ("CQ DX", "RA9YER", "MO05", "CQ DX RA9YER MO05"),
+        ("CQ 123", "G4ABC", "IO91", "CQ 123 G4ABC IO91"),
+        ("QRZ", "PA0XYZ", "JO22", "QRZ PA0XYZ JO22"),
+        ("K1ABC", "W9XYZ", "+07", "K1ABC W9XYZ +07"),
+        ("K1ABC", "W9XYZ", "", "K1ABC W9XYZ"),
+    ]
+    for c1, c2, extra, want in cases:
+        ok, text = _decode(H, t, pack77.pack_standard(c1, c2, extra))
+        assert ok and text == want, (want, text)
+    ok, text = _decode(H, t, pack77.pack_standard("K1ABC", "W9XYZ", "EN37", i3=1, p1=1))
+    assert ok and text == "K1ABC/R W9XYZ EN37"
+    ok, text = _decode(H, t, pack77.pack_standard("G4ABC", "PA0XYZ", "R JO22", i3=2, p2=1))
+    assert ok and text == "G4ABC PA0XYZ/P R JO22"
+    ok, _ = _decode(H, t, pack77.pack_standard("CQ", "K1ABC", "RRR"))       # "CQ K1ABC RRR" is not a message
+    assert not ok
+    H.msk144host_table_free(t)
+
+
+def test_free_text_and_telemetry(H):
+    t = H.msk144host_table_new()
+    for s in ("TNX BOB 73 GL", "HELLO WORLD", "A", "1/2+3-4.5?"):
+        ok, text = _decode(H, t, pack77.pack_free_text(s))
+        assert ok and text == s
+    ok, text = _decode(H, t, pack77.pack_telemetry("123456789ABCDEF012"))
+    assert ok and text == "123456789ABCDEF012"
+    ok, text = _decode(H, t, pack77.pack_telemetry("00000000000000ABCD"))
+    assert ok and text == "ABCD"
+    H.msk144host_table_free(t)
+
+
+def test_hashed_calls_resolve_after_being_heard(H):
+    t = H.msk144host_table_new()
+    assert H.msk144host_hash(b"K1ABC", 22) == pack77.hash_call("K1ABC", 22)
+    assert H.msk144host_hash(b"PJ4/K1ABC", 12) == pack77.hash_call("PJ4/K1ABC", 12)
+    m = pack77.pack_nonstandard("W9XYZ", "PJ4/K1ABC", flip=0, rpt=0)
+    ok, text = _decode(H, t, m)
+    assert ok and text == "<...> PJ4/K1ABC"                       # W9XYZ not heard yet
+    _decode(H, t, pack77.pack_standard("CQ", "W9XYZ", "EN37"))     # now it is
+    ok, text = _decode(H, t, m)
+    assert ok and text == "<W9XYZ> PJ4/K1ABC"
+    ok, text = _decode(H, t, pack77.pack_nonstandard("W9XYZ", "PJ4/K1ABC", flip=1, rpt=2))
+    assert ok and text == "PJ4/K1ABC <W9XYZ> RR73"
+    ok, text = _decode(H, t, pack77.pack_nonstandard("W9XYZ", "PJ4/K1ABC", cq=1))
+    assert ok and text == "CQ PJ4/K1ABC"
+    ok, text = _decode(H, t, pack77.pack_standard("<PJ4/K1ABC>", "W9XYZ", "-03"))
+    assert ok and text == "<PJ4/K1ABC> W9XYZ -03"                 # 22-bit hash of the non-standard call heard above
+    H.msk144host_table_free(t)
+
+
+def test_gate_matches_reference_rule(H):
+    for i3 in range(8):
+        for n3 in range(8):
+            b = np.zeros(77, dtype=np.uint8)
+            b[71:74] = pack77.bits_of(n3, 3)
+            b[74:77] = pack77.bits_of(i3, 3)
+            want = not ((i3 == 0 and (n3 in (1, 3, 4) or n3 > 5)) or i3 == 3 or i3 > 5)   # decode_softbits.cpp:29
+            assert bool(H.msk144host_message_gate(b.ctypes.data_as(C.c_void_p))) == want
+
+
+def test_snr_tracker(H):
+    s = H.msk144host_snr_new()
+    seg = np.full(8, 648.0, dtype=np.float32)
+    assert H.msk144host_snr_update(s, seg.ctypes.data_as(C.c_void_p)) == -8       # peak == noise
+    seg2 = seg.copy()
+    seg2[3] = 648.0 * 16
+    got = H.msk144host_snr_update(s, seg2.ctypes.data_as(C.c_void_p))
+    noise = np.float32(0.9) * np.float32(648.0) + np.float32(0.1) * np.float32(seg2.sum() / 8)
+    assert got == int(10 * np.log10(seg2.max() / noise - 1))
+    # the noise floor follows at least a tenth of the mean, so peak/noise <= 80: 10log10(79) -> 18
+    seg3 = np.full(8, 10.0, dtype=np.float32)
+    seg3[0] = 1e9
+    assert H.msk144host_snr_update(s, seg3.ctypes.data_as(C.c_void_p)) == 18
+    # falling mean: the floor drops at once, a flat window clamps at the lower bound again
+    assert H.msk144host_snr_update(s, seg.ctypes.data_as(C.c_void_p)) == -8
+    H.msk144host_snr_free(s)
+
+
+def _post(H, table, cands, snr=5, quirk=1):
+    arr = (Accepted * len(cands))()
+    for a, (f0, navg, nbad, pidx, bits) in zip(arr, cands):
+        a.f0, a.num_avg, a.nbadsync, a.pattern_idx = f0, navg, nbad, pidx
+        a.bits[:] = list(bits)
+    out = C.create_string_buffer(8192)
+    n = H.msk144host_postprocess(table, arr, len(cands), snr, quirk, out, len(out))
+    lines = out.value.decode().split("\n") if n else []
+    return [re.sub(r"date=\d{14}", "date=X", l) for l in lines]
+
+
+def test_result_filter_and_output_format(H):
+    t = H.msk144host_table_new()
+    m1 = pack77.pack_standard("CQ", "K1ABC", "FN42")
+    cands = [(1502.0, 3, 1, 2, m1), (1504.0, 1, 2, 0, m1), (1504.0, 1, 0, 0, m1), (1506.0, 2, 0, 1, m1)]
+    lines = _post(H, t, cands, snr=-3)
+    assert lines == ["***  snr=-3; f0=  1504; num_avg=1; nbadsync=0; pattern_idx=0; date=X; msg='CQ K1ABC FN42'; "]
+    lines = _post(H, t, [(1499.5, 6, 1, 5, m1)], snr=12)
+    assert lines == ["***  snr=12; f0=1499.5; num_avg=6; nbadsync=1; pattern_idx=5; date=X; msg='CQ K1ABC FN42'; "]
+    H.msk144host_table_free(t)
+
+
+def test_decode_cache_quirk_vs_strict(H):
+    """main.cu:437-445: the cache comparator is always false, so the first accepted candidate's text (or
+    failure) is applied to every accepted candidate of the window."""
+    t = H.msk144host_table_new()
+    m1 = pack77.pack_standard("CQ", "K1ABC", "FN42")
+    m2 = pack77.pack_standard("CQ", "W9XYZ", "EN37")
+    bad = pack77.pack_standard("CQ", "K1ABC", "RRR")                 # passes the gate, fails unpack
+    two = [(1500.0, 1, 0, 0, m1), (1510.0, 1, 0, 0, m2)]
+    assert [l.split("msg=")[1] for l in _post(H, t, two, quirk=1)] == ["'CQ K1ABC FN42'; "]
+    assert [l.split("msg=")[1] for l in _post(H, t, two, quirk=0)] == ["'CQ K1ABC FN42'; ", "'CQ W9XYZ EN37'; "]   # lexicographic
+    assert _post(H, t, [(1500.0, 1, 0, 0, bad), (1510.0, 1, 0, 0, m2)], quirk=1) == []
+    assert len(_post(H, t, [(1500.0, 1, 0, 0, bad), (1510.0, 1, 0, 0, m2)], quirk=0)) == 1
+    H.msk144host_table_free(t)
