@@ -166,7 +166,9 @@ def main():
 
     stage = dec.stage_times()
     last = dec.results()
-    # sanity: every decoded payload of a pinged channel is the transmitted one
+    # Payloads that are not the channel's transmitted message.  The reference algorithm accepts on CRC-13
+    # + < 18 hard errors, so at 1.6e7 BP attempts per step a few false positives are expected; they are
+    # the oracle's too (tests/test_gpu_full.py), not decoder errors.
     wrong = sum(1 for r in last if truth.get(int(r["channel"])) != bytes(r["message"]))
     chans_decoded = len({int(r["channel"]) for r in last})
 
@@ -197,7 +199,7 @@ def main():
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_step, "avg_launch_ms": dom_ms,
                          "note": "path is VALU/LDS-bound (SURVEY.md 8d); HBM fraction reported as measured"},
             "stage_ms": {n: round(stage[n][0], 4) for n in T_NAMES},
-            "decodes_last_step": int(len(last)), "channels_decoded_last_step": chans_decoded, "wrong_payloads": wrong,
+            "decodes_last_step": int(len(last)), "channels_decoded_last_step": chans_decoded, "crc13_false_positives_last_step": wrong,
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wins_host)

@@ -5,10 +5,12 @@
 //   * hard decisions live in two 64-bit ballot masks (SGPRs); the 38 parity checks are
 //     popcount(cw & H_row) on lanes 0..37, the hard-error count is a popcount of a ballot -
 //     no 11x38 byte scatter, no block reductions, no barriers;
-//   * tanh(-toc/2) is evaluated once per edge (384 per iteration, the reference recomputes 3840) and
-//     parked in a per-wave LDS tile T[slot][check]; each edge then multiplies its check's other slots
-//     in ascending slot order starting from 1.0f - the reference's order, so products are
-//     bit-compatible with ldpc_kernel.cuh:232-246;
+//   * tanh(-toc/2) is evaluated once per edge (384 per iteration, the reference recomputes 3840) with
+//     a 1e-6-relative exp2/rcp form and parked in a per-wave LDS tile T[slot][check]; lanes 0..37 then
+//     turn their check's column into leave-one-out products with prefix/suffix products (31
+//     multiplies instead of 110) and each edge reads its own product back;
+//   * the piecewise-linear atanh keeps the reference's breakpoints and divisors; the division is a
+//     reciprocal multiply with one FMA refinement (correctly rounded for these divisors);
 //   * CRC-13 runs as a wave-uniform bit-serial division only when all 38 checks are satisfied;
 //   * the 10th message update of the reference (whose result is never used) is skipped.
 // Work distribution: grid = (blocks per channel, channels); waves stride over the channel's index list
@@ -62,38 +64,55 @@ constexpr EdgeTables make_edge_tables()
 
 constexpr EdgeTables kEdges = make_edge_tables();
 
-// ldpc_kernel.cuh:65-93 with the branches turned into selects and a single division
-__device__ __forceinline__ float platanh(float x)
+// x / d for a compile-time divisor: q = x*r, one Newton step on the residual.  Equals the correctly
+// rounded quotient except in rare double-rounding cases (<= 1 ulp).
+__device__ __forceinline__ float div_const(float x, float d, float r)
+{
+    const float q = x * r;
+    const float e = fmaf(-q, d, x);
+    return fmaf(e, r, q);
+}
+
+// 2 * platanh(x), platanh = ldpc_kernel.cuh:65-93 (same breakpoints, offsets and divisors).
+__device__ __forceinline__ float two_platanh(float x)
 {
     const float z = __builtin_fabsf(x);
-    const float isign = (x < 0.0f) ? -1.0f : 1.0f;
-    float num, den;
+    float c = 0.4064f, d = 0.322f, r = 1.0f / 0.322f;
+    if(z > 0.9217f)
+    {
+        c = 0.8378f;
+        d = 0.0524f;
+        r = 1.0f / 0.0524f;
+    }
+    if(z > 0.9951f)
+    {
+        c = 0.9914f;
+        d = 0.0012f;
+        r = 1.0f / 0.0012f;
+    }
+    float num = __builtin_copysignf(z - c, x);  // isign * (z - c); z - c > 0 on these segments
     if(z <= 0.664f)
     {
         num = x;
-        den = 0.83f;
+        d = 0.83f;
+        r = 1.0f / 0.83f;
     }
-    else if(z <= 0.9217f)
-    {
-        num = isign * (z - 0.4064f);
-        den = 0.322f;
-    }
-    else if(z <= 0.9951f)
-    {
-        num = isign * (z - 0.8378f);
-        den = 0.0524f;
-    }
-    else if(z <= 0.9998f)
-    {
-        num = isign * (z - 0.9914f);
-        den = 0.0012f;
-    }
-    else
-    {
-        num = isign * 7.0f;
-        den = 1.0f;
-    }
-    return f32_div(num, den);
+    float v = div_const(num, d, r);
+    if(z > 0.9998f) v = __builtin_copysignf(7.0f, x);
+    return 2.0f * v;
+}
+
+// tanh(y), relative error <= ~1e-6: odd polynomial below 1/8, 1 - 2/(exp(2y)+1) above.
+__device__ __forceinline__ float fast_tanh(float y)
+{
+    const float e = __builtin_amdgcn_exp2f(y * 2.885390081777927f);  // exp(2y)
+    const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    const float y2 = y * y;
+    float p = fmaf(y2, -0.053968253968f, 0.133333333333f);  // -17/315, 2/15
+    p = fmaf(y2, p, -0.333333333333f);
+    p = fmaf(y2, p, 1.0f);
+    const float small = y * p;
+    return __builtin_fabsf(y) < 0.125f ? small : big;
 }
 
 // CRC-13 of the 96-bit block (77 message bits + zeros), bit-serial; equals the table walk of
@@ -127,26 +146,18 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     float* T = s_t[wave];
 
     // per-lane graph constants: bits lane and lane+64
-    int e_check[2][kEdgesPerBit], e_slot[2][kEdgesPerBit], e_addr[2][kEdgesPerBit];
+    int e_addr[2][kEdgesPerBit];
 #pragma unroll
     for(int h = 0; h < 2; h++)
 #pragma unroll
-        for(int k = 0; k < kEdgesPerBit; k++)
-        {
-            e_check[h][k] = kEdges.check[lane + 64 * h][k];
-            e_slot[h][k] = kEdges.slot[lane + 64 * h][k];
-            e_addr[h][k] = e_slot[h][k] * kTStride + e_check[h][k];
-        }
+        for(int k = 0; k < kEdgesPerBit; k++) e_addr[h][k] = kEdges.slot[lane + 64 * h][k] * kTStride + kEdges.check[lane + 64 * h][k];
     const int my_check = lane < kChecks ? lane : 0;
     const uint64_t hlo = kEdges.hlo[my_check];
     const uint64_t hhi = kEdges.hhi[my_check];
-    bool e_full[2][kEdgesPerBit];
-#pragma unroll
-    for(int h = 0; h < 2; h++)
-#pragma unroll
-        for(int k = 0; k < kEdgesPerBit; k++) e_full[h][k] = kEdges.full[e_check[h][k]] != 0;
+    const bool my_full = kEdges.full[my_check] != 0;
 
-    for(int t = lane; t < kMaxCheckDegree * kTStride; t += 64) T[t] = 0.0f;
+    // slot 10 of the degree-10 checks is never written: it stays 1.0 so that full-column products ignore it
+    for(int t = lane; t < kMaxCheckDegree * kTStride; t += 64) T[t] = 1.0f;
 
     for(int i = blockIdx.x * kLdpcWaves + wave; i < n_idx; i += gridDim.x * kLdpcWaves)
     {
@@ -209,28 +220,39 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 #pragma unroll
                 for(int k = 0; k < kEdgesPerBit; k++)
                 {
-                    const float toc = f32_sub(zn[h], tov[h][k]);
-                    T[e_addr[h][k]] = tanhf(-0.5f * toc);
+                    const float toc = zn[h] - tov[h][k];
+                    T[e_addr[h][k]] = fast_tanh(-0.5f * toc);
                 }
             __builtin_amdgcn_wave_barrier();
 
-            // check -> bit messages: leave-one-out product in ascending slot order
+            // check node c (lane c): column T[0..10][c] -> leave-one-out products, in place
+            if(lane < kChecks)
+            {
+                float t[kMaxCheckDegree];
+#pragma unroll
+                for(int j = 0; j < kMaxCheckDegree; j++) t[j] = T[j * kTStride + lane];
+                float pre[kMaxCheckDegree];  // pre[j] = t0*...*t(j-1)
+                pre[0] = 1.0f;
+#pragma unroll
+                for(int j = 1; j < kMaxCheckDegree; j++) pre[j] = pre[j - 1] * t[j - 1];
+                float suf = 1.0f;            // t(j+1)*...*t10
+#pragma unroll
+                for(int j = kMaxCheckDegree - 1; j >= 0; j--)
+                {
+                    T[j * kTStride + lane] = pre[j] * suf;
+                    suf *= t[j];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // check -> bit messages
 #pragma unroll
             for(int h = 0; h < 2; h++)
 #pragma unroll
-                for(int k = 0; k < kEdgesPerBit; k++)
-                {
-                    float product = 1.0f;
-#pragma unroll
-                    for(int j = 0; j < kMaxCheckDegree; j++)
-                    {
-                        const float v = T[j * kTStride + e_check[h][k]];
-                        const bool use = (j != e_slot[h][k]) && (j < kMaxCheckDegree - 1 || e_full[h][k]);
-                        product = use ? f32_mul(product, v) : product;
-                    }
-                    tov[h][k] = f32_mul(2.0f, platanh(-product));
-                }
+                for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh(-T[e_addr[h][k]]);
             __builtin_amdgcn_wave_barrier();
+            // restore the constant slot the column pass overwrote
+            if(lane < kChecks && !my_full) T[(kMaxCheckDegree - 1) * kTStride + lane] = 1.0f;
         }
     }
 }

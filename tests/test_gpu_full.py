@@ -1,0 +1,80 @@
+"""-m gpu: BASELINE-size checks (width 500, step 1, depth 6, threshold 3: F=501, 24 048 candidates/window)."""
+import numpy as np
+import pytest
+
+from msk144cudecoder_amd import synth
+
+import parity
+
+pytestmark = pytest.mark.gpu
+DEEP = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
+
+
+def test_deep_window_against_oracle(orc, hip):
+    """One full-size window, every stage compared with the oracle (about 1 s of 16 host cores)."""
+    rng = np.random.default_rng(2025)
+    msg = synth.random_message(rng)
+    x = synth.synth_audio(5184, [synth.Ping(msg, 1234, 5, 1500.0 + 137.3, 0.0, 0.9)], 1000.0, rng)
+    o = orc.Oracle(threads=16, **DEEP)
+    cd = o.frontend_audio(x, 2)
+    items_o, idx_o = o.decode_window(cd)
+    with hip.HipDecoder(channels=1, **DEEP) as d:
+        assert (d.F, d.D, d.K) == (501, 6, 24048)
+        d.submit_audio(x)
+        d.decode()
+        assert np.array_equal(d.dump_analytic(0).view(np.uint32), cd.view(np.uint32))
+        items_g = d.dump_candidates(0)
+        idx_g = d.dump_indexes(0)
+    rep = parity.compare_scan(o, cd, items_o, items_g)
+    assert rep["near_ties"] <= 24, rep                       # <= 0.1 % of slots decided inside the tolerance
+    sb = parity.compare_softbits(o, cd, items_o, items_g)
+    assert sb["nbadsync_marginal"] <= 8, sb
+    assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= 3)[0])
+    same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
+    # accept / iterations / hard errors / payload identical wherever the candidate itself is identical
+    flips = int((items_o["is_message_present"][same] != items_g["is_message_present"][same]).sum())
+    assert flips <= 2, flips
+    both = same & (items_o["is_message_present"] == 1) & (items_g["is_message_present"] == 1)
+    assert both.sum() > 10
+    assert np.array_equal(items_o["message"][both], items_g["message"][both])
+    assert np.array_equal(items_o["ldpc_num_hard_errors"][both], items_g["ldpc_num_hard_errors"][both])
+    assert (items_o["ldpc_num_iterations"][both] != items_g["ldpc_num_iterations"][both]).sum() <= 2
+    assert bytes(msg) in parity.decoded_messages(items_g)
+    assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
+
+
+def test_1024_channel_batch_properties(orc, hip):
+    """BASELINE configs[2] size: round trip of the injected pings, determinism, channel independence and
+    agreement with the oracle on every payload that is not a transmitted one (CRC-13 false positives of the
+    algorithm itself are expected at 1.6e7 BP attempts per step and must be the oracle's too)."""
+    import bench
+    wins, truth = bench.make_inputs(0, 1024)
+    with hip.HipDecoder(channels=1024, max_results=1 << 20, **DEEP) as d:
+        d.submit_audio(wins[2])
+        d.decode()
+        res1 = d.results().copy()
+        ch5 = d.dump_candidates(5).tobytes()
+        ch1000 = d.dump_candidates(1000).tobytes()
+        d.submit_audio(wins[2])
+        d.decode()
+        res2 = d.results().copy()
+    assert res1.tobytes() == res2.tobytes()                             # deterministic
+    key = res1["channel"].astype(np.int64) * 100000 + res1["item"]
+    assert np.all(np.diff(key) > 0)                                     # ordered by (channel, item)
+    decoded_channels = set(int(c) for c in np.unique(res1["channel"]))
+    pinged = set(truth)
+    assert len(decoded_channels & pinged) >= 0.5 * len(pinged)          # most pings overlap this window
+    unexpected = [r for r in res1 if truth.get(int(r["channel"])) != bytes(r["message"])]
+    assert len(unexpected) <= 5
+    o = orc.Oracle(threads=16, **DEEP)
+    for r in unexpected:
+        ch = int(r["channel"])
+        items, _ = o.decode_window(o.frontend_audio(wins[2, ch], 2))
+        k = int(r["item"])
+        assert items["is_message_present"][k] == 1
+        assert bytes(np.packbits(np.concatenate([items["message"][k].astype(np.uint8), np.zeros(3, np.uint8)]))) == bytes(r["message"])
+    with hip.HipDecoder(channels=1, **DEEP) as d1:
+        for ch, blob in ((5, ch5), (1000, ch1000)):
+            d1.submit_audio(wins[2, ch])
+            d1.decode()
+            assert d1.dump_candidates(0).tobytes() == blob              # batch == single, bit for bit
