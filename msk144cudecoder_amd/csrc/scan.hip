@@ -1,6 +1,6 @@
 // sync_scan: sync-word correlation over frequency x time offset x averaging pattern.
 //
-// Replaces scan_kernel (scan_kernel.cuh:27-393).  One workgroup per
+// Replaces scan_kernel (scan_kernel.cuh:27-393).  One workgroup (9 waves) per
 // (channel, frequency hypothesis).  The reference evaluates, for each of 5376 positions and each
 // pattern, 42 taps x 2*num_avg folded samples; here the linearity of the correlation is used:
 //
@@ -8,16 +8,28 @@
 //   S(pos,p)  = sum_{m in mask_p} C[(pos+864m) mod N] + C[(pos+864m+336) mod N]
 //   xb        = |S|
 //
-// cdat2 is the window mixed down with exactly the reference's float phase
-// phi = ((float(n)*2pi)*f0)/12000 (scan_kernel.cuh:54), so the only deviations from the reference
-// are float re-association of a linear sum and sincos/sqrt ulps (~1e-6 relative on xb).
-// Patterns 0..5 are nested prefixes (msk_context.cuh:231-236): S is accumulated across them.
+// cdat2 is the window mixed down with exactly the reference's float phase (scan_kernel.cuh:54), so
+// the only deviations from the reference are float re-association of a linear sum and sincos/sqrt ulps
+// (~1e-6 relative on xb).  Patterns 0..5 are nested prefixes (msk_context.cuh:231-236): S is
+// accumulated across them.
 //
-// Top-8 rule: per 256-position slice the arg-max (lowest position wins ties), then the 8-slot
-// replacement rule in slice order, exactly as scan_kernel.cuh:140-353; the 64-lane arg-max is a DPP
-// max + ballot instead of 32-lane shuffle trees.
+// Phases (LDS: one 5184+41 complex buffer, 44 KB per workgroup -> 3 workgroups per CU):
+//  1. mix the window into LDS (custom ~25-instruction sincos, mix.h);
+//  2. C[n]: every thread owns 9 consecutive outputs and streams the 50 samples they need through
+//     registers (50 ds_read_b64 for 378 complex MACs; lane stride 9 samples = 18 dwords is conflict-free
+//     for ds_read_b64).  The 42 taps are +-pp[i] with compile-time signs (msk_context.cuh:188-196) so only
+//     the 12 half-sine values sit in SGPRs; the 7 taps that are exactly zero (pp[0]) are skipped.  After a
+//     barrier C overwrites the window in place;
+//  3. fold + |S|^2 per pattern; each wave takes 128-position half-slices, pre-reduces the lane's two
+//     positions, then one DPP max + ballot per (half-slice, pattern).  No barrier in this phase (the
+//     reference has 4 per slice).  Lowest position wins exact ties, as the reference's strict-> trees;
+//  4. one lane per pattern: slice maximum = best of two halves, xb = sqrt (correctly rounded), then the
+//     reference's 8-slot replacement rule in slice order (scan_kernel.cuh:276-353).
 #include "msk144_kernels.h"
+#include "mix.h"
 #include "wave64.h"
+
+#include <utility>
 
 namespace msk144
 {
@@ -25,30 +37,87 @@ namespace msk144
 namespace
 {
 
-constexpr int kScanThreads = 512;
+constexpr int kOutPerThread = 9;
+constexpr int kScanThreads = kWindowSamples / kOutPerThread;  // 576 = 9 waves: one pass, in-place C
 constexpr int kScanWaves = kScanThreads / 64;
-constexpr int kChunksPerSlice = kSlicePositions / 64;         // 4 wave-chunks per slice
-constexpr int kChunks = kScanSlices * kChunksPerSlice;        // 84
-constexpr int kWrapPad = kSyncTaps - 1;                       // cdat2 is extended by 41 wrapped samples
+constexpr int kChunk = 128;                                   // positions per wave work unit
+constexpr int kChunksPerSlice = kSlicePositions / kChunk;     // 2
+constexpr int kChunks = kScanPositions / kChunk;              // 42
+constexpr int kWrapPad = kSyncTaps - 1;
+constexpr int kStream = kOutPerThread + kSyncTaps - 1;        // 50 samples feed 9 outputs
+static_assert(kScanThreads % 64 == 0 && kScanThreads * kOutPerThread == kWindowSamples, "one in-place pass");
+
+// cb42[k] = (sign_re(k) * pp[k % 12], sign_im(k) * pp[(k + 6) % 12])   (msk_context.cuh:188-196)
+constexpr int tap_re_pp(int k) { return k % 12; }
+constexpr int tap_im_pp(int k) { return (k + 6) % 12; }
+constexpr int tap_re_sign(int k) { return kSync8Pm[2 * (k / 12) + 1]; }
+constexpr int tap_im_sign(int k) { return kSync8Pm[2 * ((k + 6) / 12)]; }
 
 struct ScanArgs
 {
     DeviceStore st;
-    SyncTemplate tpl;
+    float pp[12];
     int total_tiles;
     int tiles_per_xcd;
 };
 
-__device__ __forceinline__ int wrap_window(int i)
+// One tap of one output, everything about the tap resolved at compile time:
+// conj(x)*cb[k] = (x.x*re + x.y*im) + i(x.x*im - x.y*re), re = +-pp[k%12], im = +-pp[(k+6)%12].
+template<int J, int R>
+__device__ __forceinline__ void tap_mac(const float2 x, float (&cr)[kOutPerThread], float (&ci)[kOutPerThread], const float (&pp)[12])
 {
-    return i >= kWindowSamples ? i - kWindowSamples : i;
+    constexpr int k = J - R;
+    if constexpr(k >= 0 && k < kSyncTaps)
+    {
+        if constexpr(tap_re_pp(k) != 0)
+        {
+            const float re = pp[tap_re_pp(k)];
+            if constexpr(tap_re_sign(k) > 0)
+            {
+                cr[R] = fmaf(x.x, re, cr[R]);
+                ci[R] = fmaf(-x.y, re, ci[R]);
+            }
+            else
+            {
+                cr[R] = fmaf(-x.x, re, cr[R]);
+                ci[R] = fmaf(x.y, re, ci[R]);
+            }
+        }
+        if constexpr(tap_im_pp(k) != 0)
+        {
+            const float im = pp[tap_im_pp(k)];
+            if constexpr(tap_im_sign(k) > 0)
+            {
+                cr[R] = fmaf(x.y, im, cr[R]);
+                ci[R] = fmaf(x.x, im, ci[R]);
+            }
+            else
+            {
+                cr[R] = fmaf(-x.y, im, cr[R]);
+                ci[R] = fmaf(-x.x, im, ci[R]);
+            }
+        }
+    }
+}
+
+template<int J, int... R>
+__device__ __forceinline__ void feed_sample(const float2 x, float (&cr)[kOutPerThread], float (&ci)[kOutPerThread], const float (&pp)[12],
+                                            std::integer_sequence<int, R...>)
+{
+    (tap_mac<J, R>(x, cr, ci, pp), ...);
+}
+
+template<int... J>
+__device__ __forceinline__ void stream_all(const float2* __restrict__ xs, float (&cr)[kOutPerThread], float (&ci)[kOutPerThread], const float (&pp)[12],
+                                           std::integer_sequence<int, J...>)
+{
+    (feed_sample<J>(xs[J], cr, ci, pp, std::make_integer_sequence<int, kOutPerThread>{}), ...);
 }
 
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 {
-    __shared__ float2 s_x[kWindowSamples + kWrapPad + 7];  // mixed window (+ wrap)
-    __shared__ float2 s_c[kWindowSamples];                 // single-frame correlation C[n]
-    __shared__ float s_wxb[kScanDepthMax][kChunks];        // per (pattern, wave-chunk) maximum
+    __shared__ float2 s_buf[kWindowSamples + kWrapPad + 7];  // mixed window, later C[n] in place
+    __shared__ float s_wv[kScanDepthMax][kChunks];           // per (pattern, half-slice) max |S|^2
     __shared__ uint32_t s_wpos[kScanDepthMax][kChunks];
 
     // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
@@ -65,85 +134,92 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 
     // ---- 1. mix down by the hypothesis frequency (scan_kernel.cuh:45-69) ----
     const float f0 = -1.0f * a.st.freq[b];
-    const float twopi = 2.0f * 3.14159265358979323846f;
     const float2* __restrict__ cdat = a.st.analytic + static_cast<size_t>(ch) * kWindowSamples;
-    for(int n = tid; n < kWindowSamples; n += kScanThreads)
-    {
-        const float phi = f32_div(f32_mul(f32_mul(static_cast<float>(n), twopi), f0), kSampleRate);
-        float sn, cs;
-        sincosf(phi, &sn, &cs);
-        const float2 x = cdat[n];
-        float2 y;
-        y.x = cs * x.x - sn * x.y;
-        y.y = cs * x.y + sn * x.x;
-        s_x[n] = y;
-        if(n < kWrapPad) s_x[kWindowSamples + n] = y;
-    }
-    __syncthreads();
-
-    // ---- 2. C[n] = sum_k conj(x[n+k]) * cb42[k] ----
-    for(int n = tid; n < kWindowSamples; n += kScanThreads)
-    {
-        float cr = 0.0f, ci = 0.0f;
 #pragma unroll
-        for(int k = 0; k < kSyncTaps; k++)
-        {
-            const float2 y = s_x[n + k];
-            // conj(y)*cb = (y.x*re + y.y*im) + i (y.x*im - y.y*re)
-            cr = fmaf(y.x, a.tpl.re[k], cr);
-            cr = fmaf(y.y, a.tpl.im[k], cr);
-            ci = fmaf(y.x, a.tpl.im[k], ci);
-            ci = fmaf(-y.y, a.tpl.re[k], ci);
-        }
-        s_c[n] = make_float2(cr, ci);
+    for(int i = 0; i < kOutPerThread; i++)
+    {
+        const int n = tid + i * kScanThreads;
+        const float2 y = mix_sample(cdat[n], n, f0);
+        s_buf[n] = y;
+        if(n < kWrapPad) s_buf[kWindowSamples + n] = y;
     }
     __syncthreads();
 
-    // ---- 3. fold per pattern, |S|, 64-lane arg-max per wave-chunk ----
+    // ---- 2. C[n0..n0+8], n0 = 9*tid: stream 50 samples, conj(x)*cb = (x.x*re + x.y*im) + i(x.x*im - x.y*re) ----
+    {
+        float cr[kOutPerThread], ci[kOutPerThread];
+#pragma unroll
+        for(int r = 0; r < kOutPerThread; r++)
+        {
+            cr[r] = 0.0f;
+            ci[r] = 0.0f;
+        }
+        const float2* __restrict__ xs = s_buf + tid * kOutPerThread;
+        stream_all(xs, cr, ci, a.pp, std::make_integer_sequence<int, kStream>{});
+        __syncthreads();  // every thread has read its samples: C may overwrite the window
+        float2* __restrict__ cs = s_buf + tid * kOutPerThread;
+#pragma unroll
+        for(int r = 0; r < kOutPerThread; r++) cs[r] = make_float2(cr[r], ci[r]);
+    }
+    __syncthreads();
+
+    // ---- 3. fold per pattern, |S|^2, arg-max per 128-position half-slice ----
     const int D = a.st.D;
+    constexpr uint32_t kN8 = kWindowSamples * 8u;  // byte size of the ring
+    const char* __restrict__ cbytes = reinterpret_cast<const char*>(s_buf);
     for(int chunk = wave; chunk < kChunks; chunk += kScanWaves)
     {
-        const int pos = chunk * 64 + lane;  // 0..5375
-        const int q = wrap_window(pos);
-        float sr = 0.0f, si = 0.0f;
+        uint32_t q8[2];   // byte offset of the (wrapped) position
+        float sr[2], si[2];
+#pragma unroll
+        for(int j = 0; j < 2; j++)
+        {
+            const uint32_t pos = chunk * kChunk + j * 64 + lane;  // 0..5375
+            q8[j] = (pos >= static_cast<uint32_t>(kWindowSamples) ? pos - kWindowSamples : pos) * 8u;
+            sr[j] = 0.0f;
+            si[j] = 0.0f;
+        }
         for(int p = 0; p < D; p++)
         {
-            if(p < kPatternBits)
+            float v[2];
+#pragma unroll
+            for(int j = 0; j < 2; j++)
             {
-                // nested prefix masks: add frame p
-                const int ia = wrap_window(q + kFrameSamples * p);
-                const int ib = wrap_window(ia + kSecondSyncSample);
-                const float2 ca = s_c[ia];
-                const float2 cb = s_c[ib];
-                sr = (sr + ca.x) + cb.x;
-                si = (si + ca.y) + cb.y;
-            }
-            else
-            {
-                // patterns 7 and 8 (100100, 100110): rebuild from their own masks
-                sr = 0.0f;
-                si = 0.0f;
-                for(int m = 0; m < kPatternBits; m++)
+                if(p >= kPatternBits)
                 {
-                    if(kPatternMask[p][m])
-                    {
-                        const int ia = wrap_window(q + kFrameSamples * m);
-                        const int ib = wrap_window(ia + kSecondSyncSample);
-                        const float2 ca = s_c[ia];
-                        const float2 cb = s_c[ib];
-                        sr = (sr + ca.x) + cb.x;
-                        si = (si + ca.y) + cb.y;
-                    }
+                    sr[j] = 0.0f;  // patterns 7 and 8 (100100, 100110) are not prefixes: rebuild
+                    si[j] = 0.0f;
                 }
+                const int m_first = p < kPatternBits ? p : 0;
+                const int m_last = p < kPatternBits ? p : kPatternBits - 1;
+                for(int m = m_first; m <= m_last; m++)
+                {
+                    if(p >= kPatternBits && !kPatternMask[p][m]) continue;
+                    const uint32_t a8 = q8[j] + static_cast<uint32_t>(kFrameSamples * 8) * m;
+                    const uint32_t ia = min(a8, a8 - kN8);  // a8 mod ring (unsigned wrap trick)
+                    const uint32_t b8 = ia + kSecondSyncSample * 8u;
+                    const uint32_t ib = min(b8, b8 - kN8);
+                    const float2 ca = *reinterpret_cast<const float2*>(cbytes + ia);
+                    const float2 cb = *reinterpret_cast<const float2*>(cbytes + ib);
+                    sr[j] = (sr[j] + ca.x) + cb.x;
+                    si[j] = (si[j] + ca.y) + cb.y;
+                }
+                v[j] = fmaf(sr[j], sr[j], si[j] * si[j]);
             }
-            const float xb = f32_sqrt(fmaf(sr, sr, si * si));
-            const float mx = wave_max_f32(xb);
-            const unsigned long long eq = __ballot(xb == mx);
+            // lane-local best of its two positions (lower position wins ties), then across the wave
+            const bool second = v[1] > v[0];
+            const float best = second ? v[1] : v[0];
+            const float mx = wave_max_f32(best);
+            // among lanes holding the maximum, the lowest position: first halves (j=0) come before second halves
+            const unsigned long long eq0 = __ballot(best == mx && !second);
+            const unsigned long long eq1 = __ballot(best == mx && second);
             if(lane == 0)
             {
-                const int first = eq ? __builtin_ctzll(eq) : 0;  // lowest position wins ties
-                s_wxb[p][chunk] = mx;
-                s_wpos[p][chunk] = static_cast<uint32_t>(chunk * 64 + first);
+                uint32_t off = 0;
+                if(eq0) off = __builtin_ctzll(eq0);
+                else if(eq1) off = 64 + __builtin_ctzll(eq1);
+                s_wv[p][chunk] = mx;
+                s_wpos[p][chunk] = static_cast<uint32_t>(chunk * kChunk) + off;
             }
         }
     }
@@ -163,18 +239,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         }
         for(int s = 0; s < kScanSlices; s++)
         {
-            float best = s_wxb[p][s * kChunksPerSlice];
+            float best_v = s_wv[p][s * kChunksPerSlice];
             uint32_t best_pos = s_wpos[p][s * kChunksPerSlice];
 #pragma unroll
             for(int w = 1; w < kChunksPerSlice; w++)
             {
-                const float o = s_wxb[p][s * kChunksPerSlice + w];
-                if(o > best)
+                const float o = s_wv[p][s * kChunksPerSlice + w];
+                if(o > best_v)
                 {
-                    best = o;
+                    best_v = o;
                     best_pos = s_wpos[p][s * kChunksPerSlice + w];
                 }
             }
+            const float best = f32_sqrt(best_v);
             // arg-min over the stored slots, lowest slot index wins ties
             int worst = 0;
             float worst_xb = slot_xb[0];
@@ -216,7 +293,7 @@ void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t str
 {
     ScanArgs a;
     a.st = st;
-    a.tpl = tpl;
+    for(int i = 0; i < 12; i++) a.pp[i] = tpl.pp[i];
     a.total_tiles = st.channels * st.F;
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
     const int grid = a.tiles_per_xcd * 8;
