@@ -2,16 +2,23 @@
 //
 // Replaces softbits_kernel (softbits_kernel.cuh:9-249).  The reference launches one
 // 160-thread block per candidate and every block re-mixes the whole 5184-sample window; here one
-// workgroup serves all D*8 candidates of a (channel, frequency) pair, mixes the window ONCE into LDS
-// (same float phase as the scan) and then each 64-lane wave demodulates candidates on its own, with
-// no workgroup barrier after the mix.
+// workgroup (8 waves) serves all D*8 candidates of a (channel, frequency) pair, mixes the window ONCE
+// into LDS (same float phase as the scan) and then each 64-lane wave demodulates candidates on its own,
+// entirely in registers - no workgroup barrier after the mix and no LDS scratch, so the only LDS is the
+// 41.5 KB window and three workgroups (24 waves) fit a CU.
 //
-// Reduction orders follow the reference where that is free:
-//   * the 84-term phase sum uses the reference's 42 -> 32 -> 16..1 order (softbits_kernel.cuh:98-124);
-//   * the two 144-term sums reproduce sum_reduction_two_cycles on five 32-lane warps
-//     (sum_reduction.cuh:14-44): ((w0+w1)+(w2+w3))+w4.
-// The phase rotation uses conj(s)/|s| instead of atan2f + sincosf (same unit vector to ~1 ulp).
+// Register layout: the 864-sample folded frame is cut into 144 half-bit groups of 6 samples; group
+// h = lane + 64*s (s = 0,1,2) lives in lane `lane`, slot `s`.  Softbit u needs groups u-1 and u
+// (softbits_kernel.cuh:158-177: I bits 12j..12j+11, Q bits 12j-6..12j+5), so its 12-tap sum starts in
+// the lane of group u-1 (taps pp[0..5]), hops one lane with a DPP wave shift and finishes in lane
+// u%64 with taps pp[6..11] - the reference's tap order, and softbit u ends up in lane u%64 of slot u/64.
+// From there the two 144-term sums reproduce sum_reduction_two_cycles on five 32-lane warps
+// (sum_reduction.cuh:14-44): ((w0+w1)+(w2+w3))+w4, with DPP adds instead of shuffles.
+// The phase rotation uses conj(s)/|s| instead of atan2f + sincosf (same unit vector to ~1 ulp); the
+// 84-term phase sum is accumulated per lane and then across lanes (order differs from the reference's
+// 42->32->16 tree: ~1e-7 relative on a rotation angle).
 #include "msk144_kernels.h"
+#include "mix.h"
 #include "wave64.h"
 
 namespace msk144
@@ -20,12 +27,12 @@ namespace msk144
 namespace
 {
 
-constexpr int kSbThreads = 256;
+constexpr int kSbThreads = 512;
 constexpr int kSbWaves = kSbThreads / 64;
-constexpr int kFoldIters = (kFrameSamples + 63) / 64;  // 14 (13.5)
-// rotated frame kept per wave as separate re/im planes, one pad word per 12 samples so that the
-// matched-filter reads (lane stride 12 samples) hit distinct banks
-constexpr int kPlane = kFrameSamples + kFrameSamples / 12;  // 936
+constexpr int kGroup = 6;                                  // samples per half-bit group
+constexpr int kGroups = kFrameSamples / kGroup;            // 144
+constexpr int kSlots = (kGroups + 63) / 64;                // 3
+constexpr int kRunPad = kGroup - 1;                        // a 6-sample run may cross the ring end
 
 struct SoftbitsArgs
 {
@@ -35,16 +42,35 @@ struct SoftbitsArgs
     int tiles_per_xcd;
 };
 
-__device__ __forceinline__ int padded(int n)
+constexpr int kDppWaveShr1 = 0x138;  // lane l <- lane l-1 across the whole wave (GFX9 DPP)
+
+template<int kCtrl>
+__device__ __forceinline__ float dpp_add(float v)
 {
-    return n + n / 12;
+    return f32_add(v, dpp_f32<kCtrl>(v));
+}
+
+// sums of the two 32-lane halves in the reference's shuffle order (offsets 1,2,4,8,16)
+__device__ __forceinline__ void half_sums(float v, float& lo, float& hi)
+{
+    v = dpp_add<kDppQuadXor1>(v);
+    v = dpp_add<kDppQuadXor2>(v);
+    v = dpp_add<kDppRowHalfMirror>(v);
+    v = dpp_add<kDppRowMirror>(v);
+    lo = f32_add(readlane_f32(v, 0), readlane_f32(v, 16));
+    hi = f32_add(readlane_f32(v, 32), readlane_f32(v, 48));
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    float lo, hi;
+    half_sums(v, lo, hi);
+    return lo + hi;
 }
 
 __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs a)
 {
-    __shared__ float2 s_x[kWindowSamples];
-    __shared__ float s_re[kSbWaves][kPlane];
-    __shared__ float s_im[kSbWaves][kPlane];
+    __shared__ float2 s_x[kWindowSamples + kRunPad + 3];
 
     const int xcd = blockIdx.x & 7;
     const int tile = xcd * a.tiles_per_xcd + (blockIdx.x >> 3);
@@ -58,44 +84,46 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
 
     // ---- mix (softbits_kernel.cuh:27-52) ----
     const float f0 = -1.0f * a.st.freq[b];
-    const float twopi = 2.0f * 3.14159265358979323846f;
     const float2* __restrict__ cdat = a.st.analytic + static_cast<size_t>(ch) * kWindowSamples;
     for(int n = tid; n < kWindowSamples; n += kSbThreads)
     {
-        const float phi = f32_div(f32_mul(f32_mul(static_cast<float>(n), twopi), f0), kSampleRate);
-        float sn, cs;
-        sincosf(phi, &sn, &cs);
-        const float2 x = cdat[n];
-        float2 y;
-        y.x = cs * x.x - sn * x.y;
-        y.y = cs * x.y + sn * x.x;
+        const float2 y = mix_sample(cdat[n], n, f0);
         s_x[n] = y;
+        if(n < kRunPad) s_x[kWindowSamples + n] = y;
     }
     __syncthreads();
 
-    // sync template per lane: cb[lane] for lanes 0..41 (first sync word, samples 0..41) and
-    // cb[lane-16] for lanes 16..57 (second sync word: sample 336+t sits in fold slot 5, lane 16+t)
-    float cb1r = 0.0f, cb1i = 0.0f, cb2r = 0.0f, cb2i = 0.0f;
-#pragma unroll
-    for(int k = 0; k < kSyncTaps; k++)
+    // sync template for the phase estimate: the first sync word covers samples 0..41 = groups 0..6
+    // (lanes 0..6 of slot 0), the second samples 336..377 = groups 56..62 (lanes 56..62 of slot 0)
+    float cbr[kGroup], cbi[kGroup];
     {
-        if(lane == k)
+        const int g = (lane < 7) ? lane : (lane >= 56 && lane < 63) ? lane - 56 : -1;
+#pragma unroll
+        for(int t = 0; t < kGroup; t++)
         {
-            cb1r = a.tpl.re[k];
-            cb1i = a.tpl.im[k];
+            cbr[t] = 0.0f;
+            cbi[t] = 0.0f;
         }
-        if(lane == k + 16)
+#pragma unroll
+        for(int k = 0; k < kSyncTaps; k++)
         {
-            cb2r = a.tpl.re[k];
-            cb2i = a.tpl.im[k];
+            if(g == k / kGroup)
+            {
+                cbr[k % kGroup] = a.tpl.re[k];
+                cbi[k % kGroup] = a.tpl.im[k];
+            }
         }
     }
+    const bool odd = (lane & 1) != 0;
+    float pp[12];
+#pragma unroll
+    for(int i = 0; i < 12; i++) pp[i] = a.tpl.pp[i];
 
-    float* re = s_re[wave];
-    float* im = s_im[wave];
     const int D = a.st.D;
     const int ncand = D * kSlotsPerPattern;
     const size_t item0 = static_cast<size_t>(ch) * a.st.K + static_cast<size_t>(b) * ncand;
+    constexpr uint32_t kN8 = kWindowSamples * 8u;
+    const char* __restrict__ xbytes = reinterpret_cast<const char*>(s_x);
 
     for(int c = wave; c < ncand; c += kSbWaves)
     {
@@ -104,64 +132,49 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         uint32_t pos = a.st.pos[item];
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
 
-        // ---- fold the averaged frames (softbits_kernel.cuh:59-82), 864 samples in 14 registers/lane ----
-        float fr[kFoldIters], fi[kFoldIters];
+        // ---- fold the averaged frames (softbits_kernel.cuh:59-82) ----
+        float fr[kSlots][kGroup], fi[kSlots][kGroup];
 #pragma unroll
-        for(int i = 0; i < kFoldIters; i++)
-        {
-            const int n = lane + 64 * i;
-            float sr = 0.0f, si = 0.0f;
-            if(n < kFrameSamples)
+        for(int s = 0; s < kSlots; s++)
+#pragma unroll
+            for(int t = 0; t < kGroup; t++)
             {
+                fr[s][t] = 0.0f;
+                fi[s][t] = 0.0f;
+            }
+        const uint32_t lane8 = (pos + static_cast<uint32_t>(kGroup) * lane) * 8u;  // byte offset of group `lane`, frame 0
+        for(int m = 0; m < kPatternBits; m++)
+        {
+            if(!kPatternMask[p][m]) continue;  // wave-uniform
 #pragma unroll
-                for(int m = 0; m < kPatternBits; m++)
+            for(int s = 0; s < kSlots; s++)
+            {
+                if(s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) continue;  // groups 128..143 only
+                const uint32_t a8 = lane8 + static_cast<uint32_t>((kGroup * 64 * s + kFrameSamples * m) * 8);  // < 2 * ring
+                const uint32_t i8 = min(a8, a8 - kN8);
+                const float2* __restrict__ run = reinterpret_cast<const float2*>(xbytes + i8);
+#pragma unroll
+                for(int t = 0; t < kGroup; t++)
                 {
-                    if(kPatternMask[p][m])
-                    {
-                        int idx = static_cast<int>(pos) + n + kFrameSamples * m;  // < 2*5184
-                        if(idx >= kWindowSamples) idx -= kWindowSamples;
-                        const float2 v = s_x[idx];
-                        sr += v.x;
-                        si += v.y;
-                    }
+                    const float2 v = run[t];
+                    fr[s][t] += v.x;
+                    fi[s][t] += v.y;
                 }
             }
-            fr[i] = sr;
-            fi[i] = si;
         }
 
-        // ---- carrier phase from the two sync words (softbits_kernel.cuh:88-128) ----
-        // x_t = c3[t]*conj(cb[t]) on lane t (slot 0); x_{42+t} = c3[336+t]*conj(cb[t]) on lane 16+t (slot 5)
-        float x1r = fr[0] * cb1r + fi[0] * cb1i;
-        float x1i = fi[0] * cb1r - fr[0] * cb1i;
-        float x2r = fr[5] * cb2r + fi[5] * cb2i;
-        float x2i = fi[5] * cb2r - fr[5] * cb2i;
-        x2r = __shfl(x2r, lane + 16);
-        x2i = __shfl(x2i, lane + 16);
-        float rr = (lane < kSyncTaps) ? x1r + x2r : 0.0f;
-        float ri = (lane < kSyncTaps) ? x1i + x2i : 0.0f;
-        {
-            const float tr = __shfl_down(rr, 32);
-            const float ti = __shfl_down(ri, 32);
-            if(lane < 10)
-            {
-                rr += tr;
-                ri += ti;
-            }
-        }
+        // ---- carrier phase from the two sync words (softbits_kernel.cuh:88-137): sum c3[k]*conj(cb[k]) ----
+        float pr = 0.0f, pi = 0.0f;
 #pragma unroll
-        for(int size = 16; size > 0; size >>= 1)
+        for(int t = 0; t < kGroup; t++)
         {
-            const float tr = __shfl_down(rr, size);
-            const float ti = __shfl_down(ri, size);
-            if(lane < size)
-            {
-                rr += tr;
-                ri += ti;
-            }
+            pr = fmaf(fr[0][t], cbr[t], pr);
+            pr = fmaf(fi[0][t], cbi[t], pr);
+            pi = fmaf(fi[0][t], cbr[t], pi);
+            pi = fmaf(-fr[0][t], cbi[t], pi);
         }
-        const float sre = readlane_f32(rr, 0);
-        const float sim = readlane_f32(ri, 0);
+        const float sre = wave_sum(pr);
+        const float sim = wave_sum(pi);
         // cfac = conj(exp(i*atan2(im,re))) = (re, -im)/|s|
         float cr = 1.0f, ci = 0.0f;
         {
@@ -179,60 +192,55 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
             }
         }
 
-        // ---- de-rotate and park the frame in this wave's LDS planes (softbits_kernel.cuh:146-153) ----
+        // ---- de-rotate (softbits_kernel.cuh:146-153) and matched filter (:157-180) ----
+        // va = plane that STARTS a softbit in this lane (even group -> I bit u+1 -> real part,
+        // odd group -> Q bit u+1 -> imaginary part); vb = plane that FINISHES softbit u = this group.
+        float start[kSlots], soft[kSlots];
+        float vb[kSlots][kGroup];
 #pragma unroll
-        for(int i = 0; i < kFoldIters; i++)
+        for(int s = 0; s < kSlots; s++)
         {
-            const int n = lane + 64 * i;
-            if(n < kFrameSamples)
-            {
-                const int pn = padded(n);
-                re[pn] = fr[i] * cr - fi[i] * ci;
-                im[pn] = fr[i] * ci + fi[i] * cr;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- matched filter (softbits_kernel.cuh:157-180): softbit u = 2*piq + sel lives on lane u%64 ----
-        float soft[3];
-#pragma unroll
-        for(int j = 0; j < 3; j++)
-        {
-            const int u = lane + 64 * j;
             float sb = 0.0f;
-            if(u < kSoftBits)
+#pragma unroll
+            for(int t = 0; t < kGroup; t++)
             {
-                const int sel = u & 1;
-                const int piq = u >> 1;
-                int start = 12 * piq + (sel ? 0 : kFrameSamples - 6);
-                if(start >= kFrameSamples) start -= kFrameSamples;
-                const float* plane = sel ? re : im;
-#pragma unroll
-                for(int i = 0; i < 12; i++)
-                {
-                    int k = start + i;
-                    if(k >= kFrameSamples) k -= kFrameSamples;
-                    sb = fmaf(plane[padded(k)], a.tpl.pp[i], sb);
-                }
+                const float re = fr[s][t] * cr - fi[s][t] * ci;
+                const float im = fr[s][t] * ci + fi[s][t] * cr;
+                const float va = odd ? im : re;
+                vb[s][t] = odd ? re : im;
+                sb = fmaf(va, pp[t], sb);
             }
-            soft[j] = sb;
+            start[s] = sb;
         }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- normalisation (softbits_kernel.cuh:186-201) ----
-        float w_s[3], w_q[3];
 #pragma unroll
-        for(int j = 0; j < 3; j++)
+        for(int s = 0; s < kSlots; s++)
         {
-            w_s[j] = half_tree_sum_f32(soft[j]);
-            w_q[j] = half_tree_sum_f32(soft[j] * soft[j]);
+            // incoming partial sum from group h-1: lane-1 of the same slot; lane 0 takes lane 63 of the
+            // previous slot, and group 0 takes group 143 (slot 2, lane 15): the frame is circular
+            float in = dpp_f32<kDppWaveShr1>(start[s]);
+            const float edge = (s == 0) ? readlane_f32(start[kSlots - 1], kGroups - 64 * (kSlots - 1) - 1) : readlane_f32(start[s - 1], 63);
+            if(lane == 0) in = edge;
+            float sb = in;
+#pragma unroll
+            for(int t = 0; t < kGroup; t++) sb = fmaf(vb[s][t], pp[kGroup + t], sb);
+            soft[s] = (s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) ? 0.0f : sb;
         }
-        const float sum_sav = f32_add(f32_add(f32_add(readlane_f32(w_s[0], 0), readlane_f32(w_s[0], 32)),
-                                                  f32_add(readlane_f32(w_s[1], 0), readlane_f32(w_s[1], 32))),
-                                        readlane_f32(w_s[2], 0));
-        const float sum_s2av = f32_add(f32_add(f32_add(readlane_f32(w_q[0], 0), readlane_f32(w_q[0], 32)),
-                                                   f32_add(readlane_f32(w_q[1], 0), readlane_f32(w_q[1], 32))),
-                                         readlane_f32(w_q[2], 0));
+
+        // ---- normalisation (softbits_kernel.cuh:186-201), warp sums w0..w4 in the reference's order ----
+        float w_s[5], w_q[5];
+#pragma unroll
+        for(int s = 0; s < kSlots; s++)
+        {
+            float lo, hi;
+            half_sums(soft[s], lo, hi);
+            w_s[2 * s] = lo;
+            if(s < 2) w_s[2 * s + 1] = hi;
+            half_sums(f32_mul(soft[s], soft[s]), lo, hi);
+            w_q[2 * s] = lo;
+            if(s < 2) w_q[2 * s + 1] = hi;
+        }
+        const float sum_sav = f32_add(f32_add(f32_add(w_s[0], w_s[1]), f32_add(w_s[2], w_s[3])), w_s[4]);
+        const float sum_s2av = f32_add(f32_add(f32_add(w_q[0], w_q[1]), f32_add(w_q[2], w_q[3])), w_q[4]);
         const float sav = f32_div(sum_sav, 144.0f);
         const float s2av = f32_div(sum_s2av, 144.0f);
         const float ssig = f32_sqrt(f32_sub(s2av, f32_mul(sav, sav)));
@@ -253,9 +261,9 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
 
         // ---- store (softbits_kernel.cuh:204-211,244-247) ----
         float* __restrict__ llr = a.st.llr + item * kCodeBits;
-        if(lane >= 8 && lane < 56) llr[lane - 8] = f32_mul(scale, soft[0]);     // u = 8..55   -> 0..47
-        llr[48 + lane] = f32_mul(scale, soft[1]);                               // u = 64..127 -> 48..111
-        if(lane < 16) llr[112 + lane] = f32_mul(scale, soft[2]);                // u = 128..143 -> 112..127
+        if(lane >= 8 && lane < 56) llr[lane - 8] = f32_mul(scale, soft[0]);      // u = 8..55    -> 0..47
+        llr[48 + lane] = f32_mul(scale, soft[1]);                                // u = 64..127  -> 48..111
+        if(lane < 16) llr[112 + lane] = f32_mul(scale, soft[2]);                 // u = 128..143 -> 112..127
         if(lane == 0) a.st.nbadsync[item] = nbad;
     }
 }
