@@ -9,8 +9,8 @@
 //     a 1e-6-relative exp2/rcp form and parked in a per-wave LDS tile T[slot][check]; lanes 0..37 then
 //     turn their check's column into leave-one-out products with prefix/suffix products (31
 //     multiplies instead of 110) and each edge reads its own product back;
-//   * the piecewise-linear atanh keeps the reference's breakpoints and divisors; the division is a
-//     reciprocal multiply with one FMA refinement (correctly rounded for these divisors);
+//   * the piecewise-linear atanh keeps the reference's breakpoints and offsets; (z-c)/d is evaluated
+//     as (z-c)*(2/d), within 1 ulp of the reference's quotient;
 //   * CRC-13 runs as a wave-uniform bit-serial division only when all 38 checks are satisfied;
 //   * the 10th message update of the reference (whose result is never used) is skipped.
 // Work distribution: grid = (blocks per channel, channels); waves stride over the channel's index list
@@ -64,42 +64,31 @@ constexpr EdgeTables make_edge_tables()
 
 constexpr EdgeTables kEdges = make_edge_tables();
 
-// x / d for a compile-time divisor: q = x*r, one Newton step on the residual.  Equals the correctly
-// rounded quotient except in rare double-rounding cases (<= 1 ulp).
-__device__ __forceinline__ float div_const(float x, float d, float r)
-{
-    const float q = x * r;
-    const float e = fmaf(-q, d, x);
-    return fmaf(e, r, q);
-}
-
-// 2 * platanh(x), platanh = ldpc_kernel.cuh:65-93 (same breakpoints, offsets and divisors).
+// 2 * platanh(x), platanh = ldpc_kernel.cuh:65-93: same breakpoints and offsets; the reference's
+// (z - c) / d becomes (z - c) * (2/d).  z - c is exact (Sterbenz) and the product is within 1 ulp of the
+// reference's quotient - far inside what the 1e-6 tanh below already allows.
 __device__ __forceinline__ float two_platanh(float x)
 {
     const float z = __builtin_fabsf(x);
-    float c = 0.4064f, d = 0.322f, r = 1.0f / 0.322f;
+    float c = 0.0f, r = 2.0f / 0.83f;
+    if(z > 0.664f)
+    {
+        c = 0.4064f;
+        r = 2.0f / 0.322f;
+    }
     if(z > 0.9217f)
     {
         c = 0.8378f;
-        d = 0.0524f;
-        r = 1.0f / 0.0524f;
+        r = 2.0f / 0.0524f;
     }
     if(z > 0.9951f)
     {
         c = 0.9914f;
-        d = 0.0012f;
-        r = 1.0f / 0.0012f;
+        r = 2.0f / 0.0012f;
     }
-    float num = __builtin_copysignf(z - c, x);  // isign * (z - c); z - c > 0 on these segments
-    if(z <= 0.664f)
-    {
-        num = x;
-        d = 0.83f;
-        r = 1.0f / 0.83f;
-    }
-    float v = div_const(num, d, r);
-    if(z > 0.9998f) v = __builtin_copysignf(7.0f, x);
-    return 2.0f * v;
+    float v = (z - c) * r;
+    if(z > 0.9998f) v = 14.0f;
+    return __builtin_copysignf(v, x);
 }
 
 // tanh(y), relative error <= ~1e-6: odd polynomial below 1/8, 1 - 2/(exp(2y)+1) above.
@@ -184,13 +173,12 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             const int par = (__popcll(lo & hlo) + __popcll(hi & hhi)) & 1;
             const uint64_t syndrome = __ballot(lane < kChecks && par != 0);
 
-            // hard-error count (ldpc_kernel.cuh:203-204)
-            const bool bad0 = cw[0] ? !(llr[0] > 0.0f) : !(llr[0] <= 0.0f);
-            const bool bad1 = cw[1] ? !(llr[1] > 0.0f) : !(llr[1] <= 0.0f);
-            const int nhard = __popcll(__ballot(bad0)) + __popcll(__ballot(bad1));
-
             if(syndrome == 0)
             {
+                // hard-error count (ldpc_kernel.cuh:203-204); only an accepted codeword needs it
+                const bool bad0 = cw[0] ? !(llr[0] > 0.0f) : !(llr[0] <= 0.0f);
+                const bool bad1 = cw[1] ? !(llr[1] > 0.0f) : !(llr[1] <= 0.0f);
+                const int nhard = __popcll(__ballot(bad0)) + __popcll(__ballot(bad1));
                 // codeword MSB first: cw[0] -> bit 63 of m0, cw[64] -> bit 63 of m1
                 const uint64_t m0 = __brevll(lo);
                 const uint64_t m1 = __brevll(hi);

@@ -114,6 +114,7 @@ __device__ __forceinline__ void stream_all(const float2* __restrict__ xs, float 
     (feed_sample<J>(xs[J], cr, ci, pp, std::make_integer_sequence<int, kOutPerThread>{}), ...);
 }
 
+template<int kD>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 {
     __shared__ float2 s_buf[kWindowSamples + kWrapPad + 7];  // mixed window, later C[n] in place
@@ -164,45 +165,57 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     __syncthreads();
 
     // ---- 3. fold per pattern, |S|^2, arg-max per 128-position half-slice ----
-    const int D = a.st.D;
+    // kD is a template parameter: the pattern loop is straight-line code and all 4*frames LDS reads of a
+    // chunk are in flight together.  Patterns 7 and 8 (100100, 100110) reuse the frames already loaded.
+    constexpr int D = kD;
+    constexpr int kFrames = kD < kPatternBits ? kD : kPatternBits;
     constexpr uint32_t kN8 = kWindowSamples * 8u;  // byte size of the ring
     const char* __restrict__ cbytes = reinterpret_cast<const char*>(s_buf);
     for(int chunk = wave; chunk < kChunks; chunk += kScanWaves)
     {
-        uint32_t q8[2];   // byte offset of the (wrapped) position
-        float sr[2], si[2];
+        float2 ca[2][kFrames], cb[2][kFrames];
 #pragma unroll
         for(int j = 0; j < 2; j++)
         {
             const uint32_t pos = chunk * kChunk + j * 64 + lane;  // 0..5375
-            q8[j] = (pos >= static_cast<uint32_t>(kWindowSamples) ? pos - kWindowSamples : pos) * 8u;
-            sr[j] = 0.0f;
-            si[j] = 0.0f;
+            const uint32_t q8 = (pos >= static_cast<uint32_t>(kWindowSamples) ? pos - kWindowSamples : pos) * 8u;
+#pragma unroll
+            for(int m = 0; m < kFrames; m++)
+            {
+                const uint32_t a8 = q8 + static_cast<uint32_t>(kFrameSamples * 8 * m);
+                const uint32_t ia = min(a8, a8 - kN8);  // a8 mod ring (unsigned wrap trick)
+                const uint32_t b8 = ia + kSecondSyncSample * 8u;
+                const uint32_t ib = min(b8, b8 - kN8);
+                ca[j][m] = *reinterpret_cast<const float2*>(cbytes + ia);
+                cb[j][m] = *reinterpret_cast<const float2*>(cbytes + ib);
+            }
         }
+        float sr[2] = {0.0f, 0.0f}, si[2] = {0.0f, 0.0f};
+#pragma unroll
         for(int p = 0; p < D; p++)
         {
             float v[2];
 #pragma unroll
             for(int j = 0; j < 2; j++)
             {
-                if(p >= kPatternBits)
+                if(p < kPatternBits)
                 {
-                    sr[j] = 0.0f;  // patterns 7 and 8 (100100, 100110) are not prefixes: rebuild
-                    si[j] = 0.0f;
+                    sr[j] = (sr[j] + ca[j][p].x) + cb[j][p].x;  // nested prefix masks: add frame p
+                    si[j] = (si[j] + ca[j][p].y) + cb[j][p].y;
                 }
-                const int m_first = p < kPatternBits ? p : 0;
-                const int m_last = p < kPatternBits ? p : kPatternBits - 1;
-                for(int m = m_first; m <= m_last; m++)
+                else
                 {
-                    if(p >= kPatternBits && !kPatternMask[p][m]) continue;
-                    const uint32_t a8 = q8[j] + static_cast<uint32_t>(kFrameSamples * 8) * m;
-                    const uint32_t ia = min(a8, a8 - kN8);  // a8 mod ring (unsigned wrap trick)
-                    const uint32_t b8 = ia + kSecondSyncSample * 8u;
-                    const uint32_t ib = min(b8, b8 - kN8);
-                    const float2 ca = *reinterpret_cast<const float2*>(cbytes + ia);
-                    const float2 cb = *reinterpret_cast<const float2*>(cbytes + ib);
-                    sr[j] = (sr[j] + ca.x) + cb.x;
-                    si[j] = (si[j] + ca.y) + cb.y;
+                    sr[j] = 0.0f;
+                    si[j] = 0.0f;
+#pragma unroll
+                    for(int m = 0; m < kPatternBits; m++)
+                    {
+                        if(kPatternMask[p][m])
+                        {
+                            sr[j] = (sr[j] + ca[j][m].x) + cb[j][m].x;
+                            si[j] = (si[j] + ca[j][m].y) + cb[j][m].y;
+                        }
+                    }
                 }
                 v[j] = fmaf(sr[j], sr[j], si[j] * si[j]);
             }
@@ -296,8 +309,18 @@ void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t str
     for(int i = 0; i < 12; i++) a.pp[i] = tpl.pp[i];
     a.total_tiles = st.channels * st.F;
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
-    const int grid = a.tiles_per_xcd * 8;
-    hipLaunchKernelGGL(scan_kernel, dim3(grid), dim3(kScanThreads), 0, stream, a);
+    const dim3 grid(a.tiles_per_xcd * 8), block(kScanThreads);
+    switch(st.D)
+    {
+    case 1: hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(scan_kernel<2>, grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(scan_kernel<3>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL(scan_kernel<5>, grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL(scan_kernel<6>, grid, block, 0, stream, a); break;
+    case 7: hipLaunchKernelGGL(scan_kernel<7>, grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL(scan_kernel<8>, grid, block, 0, stream, a); break;
+    }
 }
 
 }  // namespace msk144
