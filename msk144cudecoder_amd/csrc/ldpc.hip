@@ -6,7 +6,7 @@
 //     popcount(cw & H_row) on lanes 0..37, the hard-error count is a popcount of a ballot -
 //     no 11x38 byte scatter, no block reductions, no barriers;
 //   * tanh(-toc/2) is evaluated once per edge (384 per iteration, the reference recomputes 3840) with
-//     a 1e-6-relative exp2/rcp form and parked in a per-wave LDS tile T[slot][check]; lanes 0..37 then
+//     a 5-instruction exp2/rcp form (absolute error ~1.5e-7) and parked in a per-wave LDS tile T[slot][check]; lanes 0..37 then
 //     turn their check's column into leave-one-out products with prefix/suffix products (31
 //     multiplies instead of 110) and each edge reads its own product back;
 //   * the piecewise-linear atanh keeps the reference's breakpoints and offsets; (z-c)/d is evaluated
@@ -66,16 +66,13 @@ constexpr EdgeTables kEdges = make_edge_tables();
 
 // 2 * platanh(x), platanh = ldpc_kernel.cuh:65-93: same breakpoints and offsets; the reference's
 // (z - c) / d becomes (z - c) * (2/d).  z - c is exact (Sterbenz) and the product is within 1 ulp of the
-// reference's quotient - far inside what the 1e-6 tanh below already allows.
+// reference's quotient.  The first two pieces (x/0.83 and (z-0.4064)/0.322) meet exactly at the 0.664
+// breakpoint and the slope increases there, so that branch is a max(); the upper breakpoints, where the
+// reference's function jumps, stay explicit selects.
 __device__ __forceinline__ float two_platanh(float x)
 {
     const float z = __builtin_fabsf(x);
-    float c = 0.0f, r = 2.0f / 0.83f;
-    if(z > 0.664f)
-    {
-        c = 0.4064f;
-        r = 2.0f / 0.322f;
-    }
+    float c = 0.4064f, r = 2.0f / 0.322f;
     if(z > 0.9217f)
     {
         c = 0.8378f;
@@ -86,22 +83,18 @@ __device__ __forceinline__ float two_platanh(float x)
         c = 0.9914f;
         r = 2.0f / 0.0012f;
     }
-    float v = (z - c) * r;
+    float v = __builtin_fmaxf(z * (2.0f / 0.83f), (z - c) * r);
     if(z > 0.9998f) v = 14.0f;
     return __builtin_copysignf(v, x);
 }
 
-// tanh(y), relative error <= ~1e-6: odd polynomial below 1/8, 1 - 2/(exp(2y)+1) above.
+// tanh(y) = 1 - 2/(exp(2y)+1) with the hardware exp2 and rcp: absolute error <= ~1.5e-7 (the
+// reference's tanhf: 6e-8 near +-1).  Relative accuracy for tiny |y| is deliberately not pursued: a small
+// factor only ever produces a small check->bit message, and messages are added to LLRs of order 1.
 __device__ __forceinline__ float fast_tanh(float y)
 {
     const float e = __builtin_amdgcn_exp2f(y * 2.885390081777927f);  // exp(2y)
-    const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-    const float y2 = y * y;
-    float p = fmaf(y2, -0.053968253968f, 0.133333333333f);  // -17/315, 2/15
-    p = fmaf(y2, p, -0.333333333333f);
-    p = fmaf(y2, p, 1.0f);
-    const float small = y * p;
-    return __builtin_fabsf(y) < 0.125f ? small : big;
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // CRC-13 of the 96-bit block (77 message bits + zeros), bit-serial; equals the table walk of
