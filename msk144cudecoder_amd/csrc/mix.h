@@ -34,10 +34,20 @@ __device__ __forceinline__ void sincos_reduced(float phi, float& sn, float& cs)
     cs = c;
 }
 
+// x / 12000 correctly rounded without the hardware division sequence (Markstein): with r = RN(1/d),
+// q = RN(x*r), e = x - q*d exactly (FMA), RN(q + e*r) is the correctly rounded quotient.
+__device__ __forceinline__ float div_sample_rate(float x)
+{
+    constexpr float r = 1.0f / kSampleRate;  // compile-time, correctly rounded
+    const float q = f32_mul(x, r);
+    const float e = fmaf(-q, kSampleRate, x);
+    return fmaf(e, r, q);
+}
+
 __device__ __forceinline__ float mix_phase(int n, float f0)
 {
     const float twopi = 2.0f * 3.14159265358979323846f;
-    return f32_div(f32_mul(f32_mul(static_cast<float>(n), twopi), f0), kSampleRate);
+    return div_sample_rate(f32_mul(f32_mul(static_cast<float>(n), twopi), f0));
 }
 
 __device__ __forceinline__ float2 mix_sample(float2 x, int n, float f0)

@@ -42,6 +42,8 @@ struct SoftbitsArgs
     int tiles_per_xcd;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int kDppWaveShr1 = 0x138;  // lane l <- lane l-1 across the whole wave (GFX9 DPP)
 
 template<int kCtrl>
@@ -133,33 +135,32 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
 
         // ---- fold the averaged frames (softbits_kernel.cuh:59-82) ----
-        float fr[kSlots][kGroup], fi[kSlots][kGroup];
+        v2f acc[kSlots][kGroup];  // (re, im) pairs: the fold adds are packed v_pk_add_f32
 #pragma unroll
         for(int s = 0; s < kSlots; s++)
 #pragma unroll
-            for(int t = 0; t < kGroup; t++)
-            {
-                fr[s][t] = 0.0f;
-                fi[s][t] = 0.0f;
-            }
-        const uint32_t lane8 = (pos + static_cast<uint32_t>(kGroup) * lane) * 8u;  // byte offset of group `lane`, frame 0
+            for(int t = 0; t < kGroup; t++) acc[s][t] = v2f{0.0f, 0.0f};
+        // byte offset of this lane's group in each slot, frame 0.  Slot 2 only has groups 128..143: lanes
+        // >= 16 re-read group 143 (harmless, their results are discarded) so the loop stays convergent.
+        uint32_t slot8[kSlots];
+#pragma unroll
+        for(int s = 0; s < kSlots; s++)
+        {
+            const int last = kGroups - 64 * s - 1;
+            const int l = lane < last ? lane : last;
+            slot8[s] = (pos + static_cast<uint32_t>(kGroup) * (l + 64 * s)) * 8u;
+        }
         for(int m = 0; m < kPatternBits; m++)
         {
             if(!kPatternMask[p][m]) continue;  // wave-uniform
 #pragma unroll
             for(int s = 0; s < kSlots; s++)
             {
-                if(s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) continue;  // groups 128..143 only
-                const uint32_t a8 = lane8 + static_cast<uint32_t>((kGroup * 64 * s + kFrameSamples * m) * 8);  // < 2 * ring
+                const uint32_t a8 = slot8[s] + static_cast<uint32_t>(kFrameSamples * m * 8);  // < 2 * ring
                 const uint32_t i8 = min(a8, a8 - kN8);
-                const float2* __restrict__ run = reinterpret_cast<const float2*>(xbytes + i8);
+                const v2f* __restrict__ run = reinterpret_cast<const v2f*>(xbytes + i8);
 #pragma unroll
-                for(int t = 0; t < kGroup; t++)
-                {
-                    const float2 v = run[t];
-                    fr[s][t] += v.x;
-                    fi[s][t] += v.y;
-                }
+                for(int t = 0; t < kGroup; t++) acc[s][t] += run[t];
             }
         }
 
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
 #pragma unroll
         for(int t = 0; t < kGroup; t++)
         {
-            pr = fmaf(fr[0][t], cbr[t], pr);
-            pr = fmaf(fi[0][t], cbi[t], pr);
-            pi = fmaf(fi[0][t], cbr[t], pi);
-            pi = fmaf(-fr[0][t], cbi[t], pi);
+            pr = fmaf(acc[0][t].x, cbr[t], pr);
+            pr = fmaf(acc[0][t].y, cbi[t], pr);
+            pi = fmaf(acc[0][t].y, cbr[t], pi);
+            pi = fmaf(-acc[0][t].x, cbi[t], pi);
         }
         const float sre = wave_sum(pr);
         const float sim = wave_sum(pi);
@@ -195,6 +196,10 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         // ---- de-rotate (softbits_kernel.cuh:146-153) and matched filter (:157-180) ----
         // va = plane that STARTS a softbit in this lane (even group -> I bit u+1 -> real part,
         // odd group -> Q bit u+1 -> imaginary part); vb = plane that FINISHES softbit u = this group.
+        // re = fr*cr - fi*ci, im = fr*ci + fi*cr: pick the coefficient pair per lane once instead of
+        // selecting per sample.
+        const float a_r = odd ? ci : cr, a_i = odd ? cr : -ci;   // va = fr*a_r + fi*a_i
+        const float b_r = odd ? cr : ci, b_i = odd ? -ci : cr;   // vb = fr*b_r + fi*b_i
         float start[kSlots], soft[kSlots];
         float vb[kSlots][kGroup];
 #pragma unroll
@@ -204,10 +209,8 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
 #pragma unroll
             for(int t = 0; t < kGroup; t++)
             {
-                const float re = fr[s][t] * cr - fi[s][t] * ci;
-                const float im = fr[s][t] * ci + fi[s][t] * cr;
-                const float va = odd ? im : re;
-                vb[s][t] = odd ? re : im;
+                const float va = fmaf(acc[s][t].y, a_i, acc[s][t].x * a_r);
+                vb[s][t] = fmaf(acc[s][t].y, b_i, acc[s][t].x * b_r);
                 sb = fmaf(va, pp[t], sb);
             }
             start[s] = sb;
