@@ -274,3 +274,59 @@ def test_device_pointer_submit_and_determinism(hip):
         d.decode()
         b = [d.dump_candidates(c).tobytes() for c in range(4)]
     assert a == b
+
+
+def test_fft_frontend_end_to_end(orc, hip):
+    """--analytic-method=1: decodes equal the oracle's (front end within tolerance, everything after compared
+    with the oracle fed by the GPU's own analytic window)."""
+    cfg = dict(center=1500.0, width=12.0, step=2.0, depth=4, nbadsync_threshold=1)
+    x, msg = _audio_window(61, snr=4.0, n_frames=5, freq=1502.0)
+    o = orc.Oracle(threads=8, **cfg)
+    with hip.HipDecoder(analytic_method=1, channels=1, **cfg) as d:
+        d.submit_audio(x)
+        d.decode()
+        cd_g = d.dump_analytic(0)
+        items_g = d.dump_candidates(0)
+    cd_o = o.frontend_audio(x, 1)
+    assert np.abs(cd_g - cd_o).max() <= 1e-5 * np.sqrt(np.mean(np.abs(cd_o) ** 2))
+    items_o, _ = o.decode_window(cd_g)            # same analytic input for both
+    parity.compare_scan(o, cd_g, items_o, items_g)
+    parity.compare_softbits(o, cd_g, items_o, items_g)
+    assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o) == {bytes(msg)}
+
+
+def test_iq_batch_low_snr(orc, hip):
+    """configs[4] shape at reduced size: IQ, low SNR, threshold 3; every channel equals its oracle decode set."""
+    cfg = dict(center=0.0, width=24.0, step=1.0, depth=6, nbadsync_threshold=3)
+    wins, msgs = [], []
+    for i in range(6):
+        w, m = _iq_window(90 + i, snr=-4.0 + i % 3, n_frames=4 + i % 3, freq=-6.0 + 2 * i, start=300 * i)
+        wins.append(w)
+        msgs.append(m)
+    o = orc.Oracle(threads=8, **cfg)
+    with hip.HipDecoder(read_mode=2, channels=6, **cfg) as d:
+        d.submit_iq(np.stack(wins))
+        d.decode()
+        got = [d.dump_candidates(c) for c in range(6)]
+    for c in range(6):
+        items_o, _ = o.decode_window(o.frontend_iq(wins[c]))
+        assert parity.decoded_messages(got[c]) == parity.decoded_messages(items_o)
+    assert sum(bytes(msgs[c]) in parity.decoded_messages(got[c]) for c in range(6)) >= 4
+
+
+def test_result_overflow_is_reported(hip):
+    """max_results smaller than the number of decodes: count is exact, list truncated, status EOVERFLOW."""
+    import ctypes as C
+    cfg = dict(center=1500.0, width=20.0, step=1.0, depth=6, nbadsync_threshold=2)
+    x, _ = _audio_window(3, snr=6.0, n_frames=6)
+    with hip.HipDecoder(channels=1, max_results=4, **cfg) as d:
+        d.submit_audio(x)
+        d.decode()
+        n = d.result_count()
+        assert n > 4
+        out = np.zeros(n, dtype=hip.RESULT_DTYPE)
+        got = C.c_int32()
+        rc = d.L.msk144_results(d.h, out.ctypes.data_as(C.c_void_p), n, C.byref(got))
+        assert rc == -5 and got.value == n                      # MSK144_EOVERFLOW, exact count
+        assert (out["item"][:4] > 0).all() and (out["item"][4:] == 0).all()
+        assert np.all(np.diff(out["item"][:4]) > 0)
