@@ -168,7 +168,7 @@ void ev_begin(msk144_handle* h, int)
 {
     if(!h->profiling) return;
     h->ev_open = ev_take(h);
-    if(h->ev_open) hipEventRecord(h->ev_open, h->stream);
+    if(h->ev_open) (void)hipEventRecord(h->ev_open, h->stream);
 }
 
 void ev_end(msk144_handle* h, int stage)
@@ -181,7 +181,7 @@ void ev_end(msk144_handle* h, int stage)
         h->ev_open = nullptr;
         return;
     }
-    hipEventRecord(e1, h->stream);
+    (void)hipEventRecord(e1, h->stream);
     h->spans_pending.push_back({stage, h->ev_open, e1});
     h->ev_open = nullptr;
 }
@@ -372,16 +372,16 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
 void msk144_destroy(msk144_handle* h)
 {
     if(!h) return;
-    if(h->stream) hipStreamSynchronize(h->stream);
-    for(void* p : h->allocs) hipFree(p);
+    if(h->stream) (void)hipStreamSynchronize(h->stream);
+    for(void* p : h->allocs) (void)hipFree(p);
     for(const auto& sp : h->spans_pending)
     {
-        hipEventDestroy(sp.e0);
-        hipEventDestroy(sp.e1);
+        (void)hipEventDestroy(sp.e0);
+        (void)hipEventDestroy(sp.e1);
     }
-    for(hipEvent_t e : h->ev_free) hipEventDestroy(e);
-    if(h->ev_open) hipEventDestroy(h->ev_open);
-    if(h->own_stream) hipStreamDestroy(h->own_stream);
+    for(hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
+    if(h->ev_open) (void)hipEventDestroy(h->ev_open);
+    if(h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 

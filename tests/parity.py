@@ -89,7 +89,6 @@ def expected_softbits(o, cd, items_o, items_g):
     leak into the softbits comparison)."""
     exp_llr = items_o["softbits_wo_sync"].copy()
     exp_nb = items_o["nbadsync"].copy()
-    sync_margin = np.full(len(items_o), np.inf)
     diff = np.nonzero(items_o["pos"] != items_g["pos"])[0]
     for k in diff:
         soft, llr, nb = o.softbits_at(cd, int(items_o["block_idx"][k]), int(items_o["pattern_idx"][k]), int(items_g["pos"][k]))

@@ -1,0 +1,62 @@
+"""-m gpu: seeded random configurations (centre, width, step, depth, threshold, read mode, front end) and random
+windows (noise only, weak or strong pings, clipped samples) - every stage against the oracle."""
+import numpy as np
+import pytest
+
+from msk144cudecoder_amd import synth
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    read_mode = 1 if rng.random() < 0.7 else 2
+    center = float(rng.choice([1500.0, 1450.0, 1537.5])) if read_mode == 1 else float(rng.choice([0.0, -12.5, 30.0]))
+    step = float(rng.choice([0.5, 1.0, 1.5, 2.0, 2.5, 3.0]))
+    width = float(rng.choice([0.0, 5.0, 9.0, 14.0, 22.0]))
+    depth = int(rng.integers(1, 9))
+    thr = int(rng.integers(0, 6))
+    method = 2 if read_mode == 2 else int(rng.choice([1, 2, 2]))
+    n_pings = int(rng.integers(0, 3))
+    pings = []
+    msgs = []
+    for _ in range(n_pings):
+        m = synth.random_message(rng, i3=int(rng.choice([0, 1, 2, 4])))
+        msgs.append(m)
+        pings.append(synth.Ping(m, int(rng.integers(0, 4000)), int(rng.integers(1, 7)), center + float(rng.uniform(-width / 2, width / 2)),
+                                float(rng.uniform(-3, 12)), float(rng.uniform(0, 6.28))))
+    if read_mode == 1:
+        sigma = float(rng.choice([300.0, 1000.0, 9000.0]))          # 9000: clips at +-32767
+        x = synth.synth_audio(5184, pings, sigma, rng)
+    else:
+        sigma = float(rng.choice([10.0, 20.0, 60.0]))               # 60: clips at +-127
+        x = synth.synth_iq(5184, pings, sigma, rng)
+    cfg = dict(center=center, width=width, step=step, depth=depth, nbadsync_threshold=thr)
+    return cfg, read_mode, method, x, msgs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration(orc, hip, seed):
+    cfg, read_mode, method, x, msgs = _case(seed)
+    o = orc.Oracle(threads=8, **cfg)
+    with hip.HipDecoder(read_mode=read_mode, analytic_method=method, channels=1, **cfg) as d:
+        assert (d.F, d.D, d.K) == (o.F, o.D, o.total_items)
+        (d.submit_audio if read_mode == 1 else d.submit_iq)(x)
+        d.decode()
+        cd_g = d.dump_analytic(0)
+        items_g = d.dump_candidates(0)
+        idx_g = d.dump_indexes(0)
+    if read_mode == 2 or method == 2:
+        cd_o = o.frontend_audio(x, 2) if read_mode == 1 else o.frontend_iq(x)
+        assert np.array_equal(cd_o.view(np.uint32), cd_g.view(np.uint32))
+    items_o, _ = o.decode_window(cd_g)
+    for b in range(o.F):
+        assert items_g["f0"][b * o.D * 8] == np.float32(o.frequency(b))
+    parity.compare_scan(o, cd_g, items_o, items_g)
+    parity.compare_softbits(o, cd_g, items_o, items_g)
+    assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= cfg["nbadsync_threshold"])[0])
+    ld = parity.compare_ldpc_against_oracle_on_gpu_llrs(orc, items_g, cfg["nbadsync_threshold"])
+    assert ld["marginal_flips"] <= 1, ld
+    assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
