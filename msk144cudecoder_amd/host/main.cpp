@@ -34,7 +34,9 @@ void usage(const char* prog)
               << " Additions of this implementation:\n"
               << "   --strict-decode             Unpack every distinct payload of a window (the reference reuses the first one).\n"
               << "   --print-bits                Append the 77-bit payload to each output line.\n"
-              << "   --device=N                  HIP device ordinal. Default 0.\n";
+              << "   --device=N                  HIP device ordinal. Default 0.\n"
+              << "   --inputs=F1,F2,...          Decode several raw streams (files or FIFOs) as one GPU batch instead of stdin;\n"
+              << "                               output lines then carry ch=<index> after the leading stars.\n";
 }
 
 const char* mode_name(int mode)
@@ -50,6 +52,7 @@ int main(int argc, char* const argv[])
 {
     DecoderOptions opt;
     bool center_set = false;
+    std::vector<std::string> input_paths;
 
     static struct option long_options[] = {{"help", no_argument, 0, 0},
                                            {"center-frequency", required_argument, 0, 0},
@@ -62,6 +65,7 @@ int main(int argc, char* const argv[])
                                            {"strict-decode", no_argument, 0, 0},
                                            {"print-bits", no_argument, 0, 0},
                                            {"device", required_argument, 0, 0},
+                                           {"inputs", required_argument, 0, 0},
                                            {0, 0, 0, 0}};
     while(true)
     {
@@ -82,6 +86,20 @@ int main(int argc, char* const argv[])
         case 8: opt.reference_cache_quirk = false; break;
         case 9: opt.print_bits = true; break;
         case 10: opt.device = atoi(optarg); break;
+        case 11:
+        {
+            std::string list(optarg);
+            size_t a = 0;
+            while(a <= list.size())
+            {
+                const size_t b = list.find(',', a);
+                const std::string item = list.substr(a, b == std::string::npos ? std::string::npos : b - a);
+                if(!item.empty()) input_paths.push_back(item);
+                if(b == std::string::npos) break;
+                a = b + 1;
+            }
+            break;
+        }
         default: usage(argv[0]); return 0;
         }
     }
@@ -104,6 +122,28 @@ int main(int argc, char* const argv[])
         return 0;
     }
 
+    // input streams: stdin (the reference's only mode) or --inputs files/FIFOs, one channel each
+    std::vector<FILE*> streams;
+    if(input_paths.empty())
+    {
+        streams.push_back(stdin);
+    }
+    else
+    {
+        for(const std::string& path : input_paths)
+        {
+            FILE* f = fopen(path.c_str(), "rb");
+            if(!f)
+            {
+                std::cerr << "Cannot open input " << path << std::endl;
+                return 2;
+            }
+            streams.push_back(f);
+        }
+    }
+    const int nch = static_cast<int>(streams.size());
+    opt.channels = nch;
+
     WindowDecoder dec(opt);
     if(!dec.ok())
     {
@@ -122,46 +162,55 @@ int main(int argc, char* const argv[])
     if(opt.read_mode == 1) std::cerr << "Analytic Method: " << opt.analytic_method << std::endl;
     std::cerr << "Badsync Threshold: " << opt.nbadsync_threshold << std::endl
               << "Frequency hypotheses: " << dec.num_freqs() << std::endl
-              << "Candidates per window: " << dec.num_freqs() * dec.scan_depth() * 8 << std::endl
-              << std::endl;
+              << "Candidates per window: " << dec.num_freqs() * dec.scan_depth() * 8 << std::endl;
+    if(nch > 1) std::cerr << "Input streams: " << nch << std::endl;
+    std::cerr << std::endl;
 
-    // window ring: first read fills 5184 samples, every later read replaces the older half
+    // window ring per stream: first read fills 5184 samples, every later read replaces the older half
     // (main.cu:271-294 audio, :337-359 IQ)
     const size_t sample_bytes = (opt.read_mode == 1) ? sizeof(int16_t) : 2 * sizeof(int8_t);
     const size_t win_bytes = MSK144_WINDOW_SAMPLES * sample_bytes;
     const size_t unit = (opt.read_mode == 1) ? sizeof(int16_t) : sizeof(int8_t);  // the reference counts items of this size
-    std::vector<unsigned char> ring(win_bytes);
+    std::vector<unsigned char> ring(win_bytes * nch, 0);
+    std::vector<bool> active(nch, true);
     bool first = true;
-    std::vector<FilteredResult> lines;
+    std::vector<std::vector<FilteredResult>> lines;
 
     while(true)
     {
-        if(first)
+        int alive = 0;
+        for(int c = 0; c < nch; c++)
         {
-            const size_t want = win_bytes / unit;
-            const size_t rc = fread(ring.data(), unit, want, stdin);
+            if(!active[c]) continue;
+            unsigned char* w = ring.data() + win_bytes * c;
+            size_t want, rc;
+            if(first)
+            {
+                want = win_bytes / unit;
+                rc = fread(w, unit, want, streams[c]);
+            }
+            else
+            {
+                const size_t half = win_bytes / 2;
+                memcpy(w, w + half, half);
+                want = half / unit;
+                rc = fread(w + half, unit, want, streams[c]);
+            }
             if(rc != want)
             {
+                if(nch > 1) std::cerr << "ch=" << c << ": ";
                 std::cerr << "Incomplete read error. rc=" << rc << std::endl;
-                break;
+                active[c] = false;
+                memset(w, 0, win_bytes);
+                continue;
             }
-            first = false;
+            alive++;
         }
-        else
-        {
-            const size_t half = win_bytes / 2;
-            memcpy(ring.data(), ring.data() + half, half);
-            const size_t want = half / unit;
-            const size_t rc = fread(ring.data() + half, unit, want, stdin);
-            if(rc != want)
-            {
-                std::cerr << "Incomplete read error. rc=" << rc << std::endl;
-                break;
-            }
-        }
+        first = false;
+        if(alive == 0) break;
 
         const auto t0 = std::chrono::steady_clock::now();
-        if(!dec.process(ring.data(), lines))
+        if(!dec.process(ring.data(), active, lines))
         {
             std::cerr << "msk144hip: " << dec.error() << std::endl;
             return 2;
@@ -173,9 +222,25 @@ int main(int argc, char* const argv[])
             std::cerr << "Warning: Working loop takes too much time: " << ms << " ms"
                       << " of " << soft_limit_ms << " ms max." << std::endl;
         }
-        for(const FilteredResult& l : lines) std::cout << l.format_line() << std::endl;
+        for(int c = 0; c < nch; c++)
+        {
+            for(const FilteredResult& l : lines[c])
+            {
+                if(nch == 1)
+                {
+                    std::cout << l.format_line() << std::endl;
+                }
+                else
+                {
+                    const std::string line = l.format_line();  // "***  snr=..." -> "***  ch=<c>; snr=..."
+                    std::cout << line.substr(0, 5) << "ch=" << c << "; " << line.substr(5) << std::endl;
+                }
+            }
+        }
     }
 
+    for(FILE* f : streams)
+        if(f != stdin) fclose(f);
     std::cout << "Done" << std::endl;
     return 0;
 }

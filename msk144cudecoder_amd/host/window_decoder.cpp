@@ -15,8 +15,10 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
     p.nbadsync_threshold = opt.nbadsync_threshold;
     p.read_mode = opt.read_mode;
     p.analytic_method = opt.analytic_method;
-    p.channels = 1;
+    p.channels = opt.channels < 1 ? 1 : opt.channels;
+    opt_.channels = p.channels;
     p.device = opt.device;
+    p.max_results = 0x7fffffff;  // clamped by the library to channels * items: the list can never overflow
     if(msk144_create(&p, &handle_) != MSK144_OK)
     {
         error_ = msk144_last_error(nullptr);
@@ -24,6 +26,10 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
         return;
     }
     msk144_geometry(handle_, &F_, &D_, &K_);
+    snr_.resize(opt_.channels);
+    filter_.resize(opt_.channels);
+    calls_.resize(opt_.channels);
+    seg_.resize(static_cast<size_t>(opt_.channels) * 8);
 }
 
 WindowDecoder::~WindowDecoder()
@@ -47,20 +53,27 @@ float WindowDecoder::right_bound() const
 
 bool WindowDecoder::process(const void* window, std::vector<FilteredResult>& lines)
 {
-    lines.clear();
-    int rc = (opt_.read_mode == 2) ? msk144_submit_iq(handle_, static_cast<const int8_t*>(window))
-                                   : msk144_submit_audio(handle_, static_cast<const int16_t*>(window));
+    std::vector<std::vector<FilteredResult>> all;
+    const bool ok = process(window, std::vector<bool>(1, true), all);
+    lines = all.empty() ? std::vector<FilteredResult>() : std::move(all[0]);
+    return ok;
+}
+
+bool WindowDecoder::process(const void* windows, const std::vector<bool>& active, std::vector<std::vector<FilteredResult>>& lines)
+{
+    const int nch = opt_.channels;
+    lines.assign(nch, {});
+    int rc = (opt_.read_mode == 2) ? msk144_submit_iq(handle_, static_cast<const int8_t*>(windows))
+                                   : msk144_submit_audio(handle_, static_cast<const int16_t*>(windows));
     if(rc == MSK144_OK) rc = msk144_decode(handle_);
-    float seg[8];
-    if(rc == MSK144_OK) rc = msk144_segment_power(handle_, seg);
+    if(rc == MSK144_OK) rc = msk144_segment_power(handle_, seg_.data());
     int32_t n = 0;
     if(rc == MSK144_OK) rc = msk144_result_count(handle_, &n);
     if(rc == MSK144_OK)
     {
         results_.resize(n > 0 ? n : 1);
         rc = msk144_results(handle_, results_.data(), static_cast<int32_t>(results_.size()), &n);
-        if(rc == MSK144_EOVERFLOW) rc = MSK144_OK;  // list truncated at max_results; keep what we have
-        if(static_cast<size_t>(n) < results_.size()) results_.resize(n);
+        results_.resize(n);
     }
     if(rc != MSK144_OK)
     {
@@ -68,36 +81,41 @@ bool WindowDecoder::process(const void* window, std::vector<FilteredResult>& lin
         return false;
     }
 
-    snr_.update(seg);  // main.cu:388
-
-    std::vector<AcceptedCandidate> accepted;
-    accepted.reserve(results_.size());
-    for(const msk144_result& r : results_)
+    // results arrive ordered by (channel, item): walk them channel by channel
+    size_t r = 0;
+    for(int c = 0; c < nch; c++)
     {
-        AcceptedCandidate c;
-        c.f0 = r.f0;
-        c.num_avg = r.num_avg;
-        c.nbadsync = r.nbadsync;
-        c.pattern_idx = r.pattern_idx;
-        unpack_bits(r.message, c.bits);
-        accepted.push_back(c);
-    }
-    lines = postprocess_window(accepted, snr_.snr_int(), opt_.reference_cache_quirk, calls_, filter_);
-    if(opt_.print_bits)
-    {
-        // debug aid: the checkable artefact is the payload, not the text
-        for(FilteredResult& l : lines)
+        std::vector<AcceptedCandidate> accepted;
+        for(; r < results_.size() && results_[r].channel == c; r++)
         {
-            for(const AcceptedCandidate& c : accepted)
+            const msk144_result& res = results_[r];
+            AcceptedCandidate a;
+            a.f0 = res.f0;
+            a.num_avg = res.num_avg;
+            a.nbadsync = res.nbadsync;
+            a.pattern_idx = res.pattern_idx;
+            unpack_bits(res.message, a.bits);
+            accepted.push_back(a);
+        }
+        if(c < static_cast<int>(active.size()) && !active[c]) continue;  // ended stream: leave its state alone
+        snr_[c].update(&seg_[static_cast<size_t>(c) * 8]);  // main.cu:388
+        lines[c] = postprocess_window(accepted, snr_[c].snr_int(), opt_.reference_cache_quirk, calls_[c], filter_[c]);
+        if(opt_.print_bits)
+        {
+            // debug aid: the checkable artefact is the payload, not the text
+            for(FilteredResult& l : lines[c])
             {
-                std::string t;
-                CallHashTable scratch;
-                if(decode_message(c.bits, scratch, t) && t == l.text)
+                for(const AcceptedCandidate& a : accepted)
                 {
-                    std::string b(77, '0');
-                    for(int i = 0; i < 77; i++) b[i] = c.bits[i] ? '1' : '0';
-                    l.text += "' bits='" + b;
-                    break;
+                    std::string t;
+                    CallHashTable scratch;
+                    if(decode_message(a.bits, scratch, t) && t == l.text)
+                    {
+                        std::string b(77, '0');
+                        for(int i = 0; i < 77; i++) b[i] = a.bits[i] ? '1' : '0';
+                        l.text += "' bits='" + b;
+                        break;
+                    }
                 }
             }
         }

@@ -25,6 +25,7 @@ struct DecoderOptions
     int read_mode = 1;
     int analytic_method = 2;
     int device = 0;
+    int channels = 1;  // independent input streams decoded together (the reference: 1)
     // The reference keys its per-window decode cache with a comparator that is always false
     // (main.cu:437-445), so every accepted candidate of a window receives the text - or the unpack
     // failure - of the FIRST accepted candidate.  true (default) reproduces that; false unpacks every
@@ -65,7 +66,14 @@ public:
     float left_bound() const;
     float right_bound() const;
 
-    // one 5184-sample window (int16 audio or interleaved int8 I/Q); returns false on a library error
+    int channels() const { return opt_.channels; }
+
+    // One 5184-sample window per channel, [channels][5184] int16 or [channels][2*5184] int8 I/Q, decoded as one
+    // batch; lines[c] = output lines of channel c.  `active[c] == false` marks a stream that has ended: its
+    // slot is still decoded (the batch shape is fixed) but its results and state are left untouched.
+    // Returns false on a library error.
+    bool process(const void* windows, const std::vector<bool>& active, std::vector<std::vector<FilteredResult>>& lines);
+    // single-stream convenience (channels == 1)
     bool process(const void* window, std::vector<FilteredResult>& lines);
 
 private:
@@ -73,10 +81,12 @@ private:
     msk144_handle* handle_ = nullptr;
     int F_ = 0, D_ = 0, K_ = 0;
     std::string error_;
-    SnrTracker snr_;
-    ResultFilter filter_;
-    CallHashTable calls_;
+    // per-stream host state, as if each stream ran in its own reference process
+    std::vector<SnrTracker> snr_;
+    std::vector<ResultFilter> filter_;
+    std::vector<CallHashTable> calls_;
     std::vector<msk144_result> results_;
+    std::vector<float> seg_;
 };
 
 }  // namespace msk144host

@@ -9,6 +9,7 @@ import pytest
 
 from msk144cudecoder_amd import synth
 
+import pack77
 from test_host import Accepted
 
 pytestmark = pytest.mark.gpu
@@ -90,3 +91,36 @@ def test_cli_iq_and_option_quirks(orc):
     assert rc == 2 and "Wrong read mode 5" in err
     rc, out, _ = _run(["--help"], b"")
     assert rc == 0 and "--nbadsync-threshold" in out
+
+
+def test_cli_multi_stream_equals_single_streams(tmp_path):
+    """--inputs=a,b,c decodes the streams as one GPU batch per hop; each channel's lines must be exactly what
+    the single-stream program prints for that file (streams of different length end independently)."""
+    rng = np.random.default_rng(80)
+    args = ["--search-width=16", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2", "--strict-decode"]
+    files, singles = [], []
+    for i, n_hops in enumerate((4, 2, 5)):
+        n = 5184 + n_hops * 2592
+        text = [("CQ", "K1ABC", "FN42"), None, ("K1ABC", "W9XYZ", "-11")][i]
+        pings = [] if text is None else [synth.Ping(pack77.pack_standard(*text), 1000 + 3000 * i, 6, 1500.0 + 2 * i, 5.0, 0.3 * i)]
+        stream = synth.synth_audio(n, pings, 1000.0, rng)
+        path = tmp_path / f"s{i}.s16"
+        path.write_bytes(stream.tobytes())
+        files.append(str(path))
+        rc, out, _ = _run(args, stream.tobytes())
+        assert rc == 0
+        singles.append([re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]])
+    assert len(singles[0]) >= 1 and len(singles[2]) >= 1 and singles[1] == []
+    assert all("msg='CQ K1ABC FN42'" in l for l in singles[0]) and all("msg='K1ABC W9XYZ -11'" in l for l in singles[2])
+    rc, out, err = _run(args + ["--inputs=" + ",".join(files)], b"")
+    assert rc == 0, err
+    lines = out.strip().split("\n")
+    assert lines[-1] == "Done"
+    per_ch = {0: [], 1: [], 2: []}
+    for l in lines[:-1]:
+        m = re.match(r"^\*\*\*  ch=(\d+); (.*)$", l)
+        assert m, l
+        per_ch[int(m.group(1))].append("***  " + re.sub(r"date=\d{14}", "date=X", m.group(2)))
+    for c in range(3):
+        assert per_ch[c] == singles[c]
+    assert err.count("Incomplete read error") == 3 and "Input streams: 3" in err
