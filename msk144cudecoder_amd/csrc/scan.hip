@@ -224,8 +224,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
             const float best = second ? v[1] : v[0];
             const float mx = wave_max_f32(best);
             // among lanes holding the maximum, the lowest position: first halves (j=0) come before second halves
-            const unsigned long long eq0 = __ballot(best == mx && !second);
-            const unsigned long long eq1 = __ballot(best == mx && second);
+            const unsigned long long eq = __ballot(best == mx);
+            const unsigned long long sec = __ballot(second);
+            const unsigned long long eq0 = eq & ~sec;
+            const unsigned long long eq1 = eq & sec;
             if(lane == 0)
             {
                 uint32_t off = 0;

@@ -55,10 +55,7 @@ __device__ __forceinline__ float dpp_add(float v)
 // sums of the two 32-lane halves in the reference's shuffle order (offsets 1,2,4,8,16)
 __device__ __forceinline__ void half_sums(float v, float& lo, float& hi)
 {
-    v = dpp_add<kDppQuadXor1>(v);
-    v = dpp_add<kDppQuadXor2>(v);
-    v = dpp_add<kDppRowHalfMirror>(v);
-    v = dpp_add<kDppRowMirror>(v);
+    v = row_sum_f32(v);
     lo = f32_add(readlane_f32(v, 0), readlane_f32(v, 16));
     hi = f32_add(readlane_f32(v, 32), readlane_f32(v, 48));
 }

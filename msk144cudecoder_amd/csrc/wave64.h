@@ -55,20 +55,49 @@ constexpr int kDppQuadXor2 = 0x4E;     // quad_perm:[2,3,0,1]
 constexpr int kDppRowHalfMirror = 0x141;
 constexpr int kDppRowMirror = 0x140;
 
-// max over the 64 lanes, returned wave-uniform.  4 DPP stages reduce each 16-lane row, then the
-// four row results are combined through readlane.  NaN operands are ignored (v_max_f32 maxNum).
+// max over the 64 lanes, returned wave-uniform.  Six fused v_max_f32_dpp steps: four reduce each
+// 16-lane row (quad xor 1, quad xor 2, half mirror, mirror), row_bcast:15 / row_bcast:31 fold the rows
+// into lane 63.  hipcc expands the builtin form into mov + nop + mov_dpp + canonicalise + max per step,
+// hence the asm; the 2 wait states a DPP read needs after a VALU write are inside the string (hipcc does
+// not insert hazard nops for asm statements).  NaN operands are ignored (v_max_f32 maxNum).
 __device__ __forceinline__ float wave_max_f32(float v)
 {
-    v = __builtin_fmaxf(v, dpp_f32<kDppQuadXor1>(v));
-    v = __builtin_fmaxf(v, dpp_f32<kDppQuadXor2>(v));
-    v = __builtin_fmaxf(v, dpp_f32<kDppRowHalfMirror>(v));
-    v = __builtin_fmaxf(v, dpp_f32<kDppRowMirror>(v));
-    const int i = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
-    return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "=&v"(r)
+                 : "v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
+}
+
+// v + (its quad/row partners): after the four steps every lane of a 16-lane row holds the row sum, added
+// in the order lane^1, lane^2, other quad pair, other half - the reference's shuffle-tree association.
+__device__ __forceinline__ float row_sum_f32(float v)
+{
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "=&v"(r)
+                 : "v"(v));
+    return r;
 }
 
 __device__ __forceinline__ float readlane_f32(float v, int lane)
