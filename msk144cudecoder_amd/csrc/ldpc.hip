@@ -88,12 +88,12 @@ __device__ __forceinline__ float two_platanh(float x)
     return __builtin_copysignf(v, x);
 }
 
-// tanh(y) = 1 - 2/(exp(2y)+1) with the hardware exp2 and rcp: absolute error <= ~1.5e-7 (the
-// reference's tanhf: 6e-8 near +-1).  Relative accuracy for tiny |y| is deliberately not pursued: a small
+// tanh(-x/2) = 1 - 2/(exp(-x)+1) with the hardware exp2 and rcp: absolute error <= ~1.5e-7 (the
+// reference's tanhf: 6e-8 near +-1).  Relative accuracy for tiny |x| is deliberately not pursued: a small
 // factor only ever produces a small check->bit message, and messages are added to LLRs of order 1.
-__device__ __forceinline__ float fast_tanh(float y)
+__device__ __forceinline__ float tanh_neg_half(float x)
 {
-    const float e = __builtin_amdgcn_exp2f(y * 2.885390081777927f);  // exp(2y)
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);  // exp(-x)
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 
             // 38 parity checks: lane c < 38 evaluates check c
             const int par = (__popcll(lo & hlo) + __popcll(hi & hhi)) & 1;
-            const uint64_t syndrome = __ballot(lane < kChecks && par != 0);
+            const uint64_t syndrome = __ballot(par != 0) & ((1ull << kChecks) - 1ull);
 
             if(syndrome == 0)
             {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                 for(int k = 0; k < kEdgesPerBit; k++)
                 {
                     const float toc = zn[h] - tov[h][k];
-                    T[e_addr[h][k]] = fast_tanh(-0.5f * toc);
+                    T[e_addr[h][k]] = tanh_neg_half(toc);
                 }
             __builtin_amdgcn_wave_barrier();
 
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                 pre[0] = 1.0f;
 #pragma unroll
                 for(int j = 1; j < kMaxCheckDegree; j++) pre[j] = pre[j - 1] * t[j - 1];
-                float suf = 1.0f;            // t(j+1)*...*t10
+                float suf = -1.0f;           // -(t(j+1)*...*t10): the column is stored NEGATED, ready for platanh(-product)
 #pragma unroll
                 for(int j = kMaxCheckDegree - 1; j >= 0; j--)
                 {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 #pragma unroll
             for(int h = 0; h < 2; h++)
 #pragma unroll
-                for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh(-T[e_addr[h][k]]);
+                for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh(T[e_addr[h][k]]);
             __builtin_amdgcn_wave_barrier();
             // restore the constant slot the column pass overwrote
             if(lane < kChecks && !my_full) T[(kMaxCheckDegree - 1) * kTStride + lane] = 1.0f;
