@@ -30,6 +30,7 @@ struct msk144_handle
 
     // device allocations
     float* d_freq = nullptr;
+    float2* d_cb42 = nullptr;
     void* d_input = nullptr;  // staging for host-submitted windows
     float2* d_twiddle = nullptr;
     float* d_fft_mask = nullptr;
@@ -311,6 +312,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     int rc = MSK144_OK;
     auto A = [&](int r) { if(rc == MSK144_OK) rc = r; };
     A(dev_alloc(h, &h->d_freq, F));
+    A(dev_alloc(h, &h->d_cb42, kSyncTaps));
     A(dev_alloc(h, &st.analytic, static_cast<size_t>(st.channels) * kWindowSamples));
     A(dev_alloc(h, &st.seg_power, static_cast<size_t>(st.channels) * 8));
     A(dev_alloc(h, &st.pos, ck));
@@ -337,8 +339,14 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     }
     if(rc != MSK144_OK) return bail(rc);
     st.freq = h->d_freq;
+    st.cb42 = h->d_cb42;
 
     bool ok = hipMemcpy(h->d_freq, h->freq_host.data(), sizeof(float) * F, hipMemcpyHostToDevice) == hipSuccess;
+    {
+        float2 cb[kSyncTaps];
+        for(int k = 0; k < kSyncTaps; k++) cb[k] = make_float2(h->tpl.re[k], h->tpl.im[k]);
+        ok = ok && hipMemcpy(h->d_cb42, cb, sizeof(cb), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && hipMemset(st.dec_flag, 0, ck) == hipSuccess;
     ok = ok && hipMemset(st.n_idx, 0, sizeof(int32_t) * st.channels) == hipSuccess;
     ok = ok && hipMemset(st.dec_count, 0, sizeof(int32_t) * st.channels) == hipSuccess;

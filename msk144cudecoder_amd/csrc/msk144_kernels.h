@@ -31,6 +31,7 @@ struct DeviceStore
     int32_t max_results;
 
     const float* freq;        // [F] Hz, host-computed as msk_context.cuh:135
+    const float2* cb42;       // [42] sync template (re, im), for kernels that index it per lane
     float2* analytic;         // [channels][5184] front-end output
     float* seg_power;         // [channels][8]
 

@@ -100,17 +100,9 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
 #pragma unroll
         for(int t = 0; t < kGroup; t++)
         {
-            cbr[t] = 0.0f;
-            cbi[t] = 0.0f;
-        }
-#pragma unroll
-        for(int k = 0; k < kSyncTaps; k++)
-        {
-            if(g == k / kGroup)
-            {
-                cbr[k % kGroup] = a.tpl.re[k];
-                cbi[k % kGroup] = a.tpl.im[k];
-            }
+            const float2 c = a.st.cb42[(g < 0 ? 0 : g) * kGroup + t];
+            cbr[t] = g < 0 ? 0.0f : c.x;
+            cbi[t] = g < 0 ? 0.0f : c.y;
         }
     }
     const bool odd = (lane & 1) != 0;
@@ -176,17 +168,17 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         // cfac = conj(exp(i*atan2(im,re))) = (re, -im)/|s|
         float cr = 1.0f, ci = 0.0f;
         {
-            const float mag = f32_sqrt(fmaf(sre, sre, sim * sim));
-            if(mag > 0.0f)
+            const float m2 = fmaf(sre, sre, sim * sim);
+            if(m2 > 0.0f)
             {
-                const float inv = 1.0f / mag;
+                const float inv = __builtin_amdgcn_rsqf(m2);  // 1 ulp: the unit phasor only needs ~1e-7
                 cr = sre * inv;
                 ci = -sim * inv;
             }
-            else if(!(mag == 0.0f))
+            else if(!(m2 == 0.0f))
             {
-                cr = mag;  // NaN propagates like the reference's atan2f/sincosf chain
-                ci = mag;
+                cr = m2;  // NaN propagates like the reference's atan2f/sincosf chain
+                ci = m2;
             }
         }
 
@@ -241,11 +233,20 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         }
         const float sum_sav = f32_add(f32_add(f32_add(w_s[0], w_s[1]), f32_add(w_s[2], w_s[3])), w_s[4]);
         const float sum_s2av = f32_add(f32_add(f32_add(w_q[0], w_q[1]), f32_add(w_q[2], w_q[3])), w_q[4]);
-        const float sav = f32_div(sum_sav, 144.0f);
-        const float s2av = f32_div(sum_s2av, 144.0f);
+        const float sav = div_by_const<144>(sum_sav);    // correctly rounded, like the reference's division
+        const float s2av = div_by_const<144>(sum_s2av);
         const float ssig = f32_sqrt(f32_sub(s2av, f32_mul(sav, sav)));
         const float sigma = 0.60f;
-        const float scale = f32_div(2.0f, f32_mul(f32_mul(ssig, sigma), sigma));
+        const float den = f32_mul(f32_mul(ssig, sigma), sigma);
+        // 2/den: reciprocal + one Newton step on the residual (Markstein form with a runtime divisor):
+        // correctly rounded except in rare double-rounding cases, 4 instructions instead of the ~10 of v_div_*
+        float scale;
+        {
+            const float r = __builtin_amdgcn_rcpf(den);
+            const float q = 2.0f * r;
+            const float e = fmaf(-q, den, 2.0f);
+            scale = fmaf(e, r, q);
+        }
 
         // ---- sync-word disagreements (softbits_kernel.cuh:214-241): bits 0..7 and 56..63 ----
         int sync_bit = -1;

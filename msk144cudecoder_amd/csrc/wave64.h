@@ -30,6 +30,17 @@ __device__ __forceinline__ float f32_div(float a, float b)
 {
     return a / b;  // correctly rounded: -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default
 }
+// x / D for a small integer constant D, correctly rounded (Markstein: r = RN(1/D), q = RN(x*r),
+// e = x - q*D exactly by FMA, result RN(q + e*r)).
+template<int D>
+__device__ __forceinline__ float div_by_const(float x)
+{
+    constexpr float d = static_cast<float>(D);
+    constexpr float r = 1.0f / d;
+    const float q = f32_mul(x, r);
+    const float e = fmaf(-q, d, x);
+    return fmaf(e, r, q);
+}
 __device__ __forceinline__ float f32_sqrt(float x)
 {
     return __builtin_sqrtf(x);  // v_sqrt_f32 + FMA refinement, correctly rounded
