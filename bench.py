@@ -185,6 +185,21 @@ def main():
                 traffic = json.load(open(tfile)).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # The bound that actually applies: VALU instruction issue.  Instruction counts per launch come from the
+        # committed SQ counter pass of this same command (profiles/r01_sq_counters.json); the rate uses the
+        # HIP-event time of THIS run.  Ceiling ~8e11 wave-instr/s (tools/ubench/valu_rates.hip).
+        valu = None
+        cfile = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
+        if os.path.exists(cfile) and channels == CHANNELS_PER_GPU:
+            try:
+                sq = json.load(open(cfile))
+                valu = {"unit": "wave-instr/s", "ceiling": 8.0e11, "source": "profiles/r01_sq_counters.json (SQ_INSTS_VALU) / stage_ms"}
+                for k in ("scan", "softbits", "ldpc"):
+                    if stage[k][0] > 0:
+                        rate = sq[k + "_kernel"]["SQ_INSTS_VALU"] / (stage[k][0] * 1e-3)
+                        valu[k + "_kernel"] = {"achieved": rate, "frac": rate / 8.0e11}
+            except Exception:
+                valu = None
         out = {
             "metric": "candidate decodes/sec (scan+softbits+LDPC), width=500 step=1 depth=6",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,6 +213,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_step, "avg_launch_ms": dom_ms,
                          "note": "path is VALU/LDS-bound (SURVEY.md 8d); HBM fraction reported as measured"},
+            "valu_issue": valu,
             "stage_ms": {n: round(stage[n][0], 4) for n in T_NAMES},
             "decodes_last_step": int(len(last)), "channels_decoded_last_step": chans_decoded, "crc13_false_positives_last_step": wrong,
         }
