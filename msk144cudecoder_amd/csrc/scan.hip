@@ -23,8 +23,10 @@
 //  3. fold + |S|^2 per pattern; each wave takes 128-position half-slices, pre-reduces the lane's two
 //     positions, then one DPP max + ballot per (half-slice, pattern).  No barrier in this phase (the
 //     reference has 4 per slice).  Lowest position wins exact ties, as the reference's strict-> trees;
-//  4. one lane per pattern: slice maximum = best of two halves, xb = sqrt (correctly rounded), then the
-//     reference's 8-slot replacement rule in slice order (scan_kernel.cuh:276-353).
+//  4. xb = sqrt (correctly rounded) of the half-slice maxima in parallel; then one wave, lane = 8*pattern +
+//     slot, runs the reference's 8-slot replacement rule in slice order (scan_kernel.cuh:276-353): slice
+//     maximum = better of two halves, arg-min over a pattern's 8 slots by three DPP min steps + ballot
+//     (lowest slot wins ties), conditional replace.  21 short steps instead of a 1300-instruction serial tail.
 #include "msk144_kernels.h"
 #include "mix.h"
 #include "wave64.h"
@@ -250,64 +252,46 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     }
     __syncthreads();
 
-    // ---- 4. per pattern: slice maxima in order, 8-slot replacement rule (scan_kernel.cuh:276-353) ----
-    if(tid < D)
+    // ---- 4a. xb = |S| for the 42*D half-slice maxima, in parallel (correctly rounded sqrt) ----
+    for(int e = tid; e < D * kChunks; e += kScanThreads)
     {
-        const int p = tid;
-        float slot_xb[kSlotsPerPattern];
-        uint32_t slot_pos[kSlotsPerPattern];
-#pragma unroll
-        for(int i = 0; i < kSlotsPerPattern; i++)
-        {
-            slot_xb[i] = 0.0f;
-            slot_pos[i] = 0u;
-        }
+        const int p = e / kChunks;
+        const int c = e - p * kChunks;
+        s_wv[p][c] = f32_sqrt(s_wv[p][c]);
+    }
+    __syncthreads();
+
+    // ---- 4b. 8-slot replacement rule in slice order (scan_kernel.cuh:276-353), one wave: lane = 8*pattern + slot ----
+    if(wave == 0)
+    {
+        const int p = lane >> 3;
+        const int slot = lane & 7;
+        const int pc = p < D ? p : 0;  // lanes of unused patterns shadow pattern 0 and store nothing
+        float my_xb = 0.0f;            // reset(): pos 0, xb 0 (scan_kernel.cuh:78-82)
+        uint32_t my_pos = 0u;
         for(int s = 0; s < kScanSlices; s++)
         {
-            float best_v = s_wv[p][s * kChunksPerSlice];
-            uint32_t best_pos = s_wpos[p][s * kChunksPerSlice];
-#pragma unroll
-            for(int w = 1; w < kChunksPerSlice; w++)
+            // slice maximum = better of its two halves, lower position on ties
+            const float v0 = s_wv[pc][2 * s], v1 = s_wv[pc][2 * s + 1];
+            const bool second = v1 > v0;
+            const float best = second ? v1 : v0;
+            const uint32_t best_pos = second ? s_wpos[pc][2 * s + 1] : s_wpos[pc][2 * s];
+            // arg-min over the 8 stored slots of this pattern, lowest slot index wins ties
+            const float mn = oct_min_f32(my_xb);
+            const unsigned long long eq = __ballot(my_xb == mn);
+            const uint32_t mine = static_cast<uint32_t>(eq >> (8 * p)) & 0xFFu;
+            const int worst = __builtin_ctz(mine | 0x100u);
+            if(slot == worst && best > my_xb)
             {
-                const float o = s_wv[p][s * kChunksPerSlice + w];
-                if(o > best_v)
-                {
-                    best_v = o;
-                    best_pos = s_wpos[p][s * kChunksPerSlice + w];
-                }
-            }
-            const float best = f32_sqrt(best_v);
-            // arg-min over the stored slots, lowest slot index wins ties
-            int worst = 0;
-            float worst_xb = slot_xb[0];
-#pragma unroll
-            for(int i = 1; i < kSlotsPerPattern; i++)
-            {
-                if(slot_xb[i] < worst_xb)
-                {
-                    worst_xb = slot_xb[i];
-                    worst = i;
-                }
-            }
-            if(best > worst_xb)
-            {
-#pragma unroll
-                for(int i = 0; i < kSlotsPerPattern; i++)
-                {
-                    if(i == worst)
-                    {
-                        slot_xb[i] = best;
-                        slot_pos[i] = best_pos;
-                    }
-                }
+                my_xb = best;
+                my_pos = best_pos;
             }
         }
-        const size_t base = static_cast<size_t>(ch) * a.st.K + (static_cast<size_t>(b) * D + p) * kSlotsPerPattern;
-#pragma unroll
-        for(int i = 0; i < kSlotsPerPattern; i++)
+        if(p < D)
         {
-            a.st.pos[base + i] = slot_pos[i];
-            a.st.xb[base + i] = slot_xb[i];
+            const size_t base = static_cast<size_t>(ch) * a.st.K + (static_cast<size_t>(b) * D + p) * kSlotsPerPattern;
+            a.st.pos[base + slot] = my_pos;
+            a.st.xb[base + slot] = my_xb;
         }
     }
 }

@@ -92,6 +92,22 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
 }
 
+// min over each aligned group of 8 lanes, result in all 8 (quad xor 1, quad xor 2, half mirror).
+__device__ __forceinline__ float oct_min_f32(float v)
+{
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "=&v"(r)
+                 : "v"(v));
+    return r;
+}
+
 // v + (its quad/row partners): after the four steps every lane of a 16-lane row holds the row sum, added
 // in the order lane^1, lane^2, other quad pair, other half - the reference's shuffle-tree association.
 __device__ __forceinline__ float row_sum_f32(float v)
