@@ -64,36 +64,43 @@ constexpr EdgeTables make_edge_tables()
 
 constexpr EdgeTables kEdges = make_edge_tables();
 
-// 2 * platanh(x), platanh = ldpc_kernel.cuh:65-93: same breakpoints and offsets; the reference's
-// (z - c) / d becomes (z - c) * (2/d).  z - c is exact (Sterbenz) and the product is within 1 ulp of the
-// reference's quotient.  The first two pieces (x/0.83 and (z-0.4064)/0.322) meet exactly at the 0.664
+// BP runs in LOG2-SCALED units: every LLR-domain quantity (llr, zn, toc, tov) carries a factor
+// log2(e), so that exp(-toc) is a bare v_exp_f32 of -toc' with no multiply in front of it.  The factor is
+// applied once per codeword to the two LLRs of a lane and is folded into the constants below; hard
+// decisions (signs) are unaffected.
+constexpr float kLog2e = 1.4426950408889634f;
+
+// log2(e) * 2 * platanh(x), platanh = ldpc_kernel.cuh:65-93: same breakpoints and offsets; the reference's
+// (z - c) / d becomes (z - c) * (2 log2e / d).  z - c is exact (Sterbenz) and the product is within 1 ulp of
+// the scaled quotient.  The first two pieces (x/0.83 and (z-0.4064)/0.322) meet exactly at the 0.664
 // breakpoint and the slope increases there, so that branch is a max(); the upper breakpoints, where the
 // reference's function jumps, stay explicit selects.
-__device__ __forceinline__ float two_platanh(float x)
+__device__ __forceinline__ float two_platanh_scaled(float x)
 {
     const float z = __builtin_fabsf(x);
-    float c = 0.4064f, r = 2.0f / 0.322f;
+    float c = 0.4064f, r = kLog2e * 2.0f / 0.322f;
     if(z > 0.9217f)
     {
         c = 0.8378f;
-        r = 2.0f / 0.0524f;
+        r = kLog2e * 2.0f / 0.0524f;
     }
     if(z > 0.9951f)
     {
         c = 0.9914f;
-        r = 2.0f / 0.0012f;
+        r = kLog2e * 2.0f / 0.0012f;
     }
-    float v = __builtin_fmaxf(z * (2.0f / 0.83f), (z - c) * r);
-    if(z > 0.9998f) v = 14.0f;
+    float v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), (z - c) * r);
+    if(z > 0.9998f) v = kLog2e * 14.0f;
     return __builtin_copysignf(v, x);
 }
 
-// tanh(-x/2) = 1 - 2/(exp(-x)+1) with the hardware exp2 and rcp: absolute error <= ~1.5e-7 (the
-// reference's tanhf: 6e-8 near +-1).  Relative accuracy for tiny |x| is deliberately not pursued: a small
-// factor only ever produces a small check->bit message, and messages are added to LLRs of order 1.
-__device__ __forceinline__ float tanh_neg_half(float x)
+// tanh(-x/2) = 1 - 2/(exp(-x)+1) for x given in log2-scaled units: exp(-x) = exp2(-x').  Hardware exp2 and
+// rcp: absolute error <= ~1.5e-7 (the reference's tanhf: 6e-8 near +-1).  Relative accuracy for tiny |x| is
+// deliberately not pursued: a small factor only ever produces a small check->bit message, and messages are
+// added to LLRs of order 1.
+__device__ __forceinline__ float tanh_neg_half_scaled(float xs)
 {
-    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);  // exp(-x)
+    const float e = __builtin_amdgcn_exp2f(-xs);
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     {
         const int item = idx[i];
         const float* __restrict__ L = st.llr + (off + item) * kCodeBits;
-        float llr[2] = {L[lane], L[lane + 64]};
+        const float llr[2] = {L[lane], L[lane + 64]};
+        const float llr_s[2] = {llr[0] * kLog2e, llr[1] * kLog2e};  // log2-scaled copy used by the message passing
         float tov[2][kEdgesPerBit] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
 
         for(int iter = 0; iter < kLdpcIterations; iter++)
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             for(int h = 0; h < 2; h++)
             {
                 const float sum = f32_add(f32_add(tov[h][0], tov[h][1]), tov[h][2]);
-                zn[h] = f32_add(llr[h], sum);
+                zn[h] = f32_add(llr_s[h], sum);
                 cw[h] = zn[h] > 0.0f;
             }
             const uint64_t lo = __ballot(cw[0]);
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                 for(int k = 0; k < kEdgesPerBit; k++)
                 {
                     const float toc = zn[h] - tov[h][k];
-                    T[e_addr[h][k]] = tanh_neg_half(toc);
+                    T[e_addr[h][k]] = tanh_neg_half_scaled(toc);
                 }
             __builtin_amdgcn_wave_barrier();
 
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 #pragma unroll
             for(int h = 0; h < 2; h++)
 #pragma unroll
-                for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh(T[e_addr[h][k]]);
+                for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh_scaled(T[e_addr[h][k]]);
             __builtin_amdgcn_wave_barrier();
             // restore the constant slot the column pass overwrote
             if(lane < kChecks && !my_full) T[(kMaxCheckDegree - 1) * kTStride + lane] = 1.0f;

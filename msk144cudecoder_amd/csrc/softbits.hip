@@ -93,18 +93,10 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
     __syncthreads();
 
     // sync template for the phase estimate: the first sync word covers samples 0..41 = groups 0..6
-    // (lanes 0..6 of slot 0), the second samples 336..377 = groups 56..62 (lanes 56..62 of slot 0)
-    float cbr[kGroup], cbi[kGroup];
-    {
-        const int g = (lane < 7) ? lane : (lane >= 56 && lane < 63) ? lane - 56 : -1;
-#pragma unroll
-        for(int t = 0; t < kGroup; t++)
-        {
-            const float2 c = a.st.cb42[(g < 0 ? 0 : g) * kGroup + t];
-            cbr[t] = g < 0 ? 0.0f : c.x;
-            cbi[t] = g < 0 ? 0.0f : c.y;
-        }
-    }
+    // (lanes 0..6 of slot 0), the second samples 336..377 = groups 56..62 (lanes 56..62 of slot 0).
+    // The 6 taps of a lane are re-read from the (L1-resident) device table for every candidate rather than
+    // kept in 12 registers: that keeps the kernel under 80 VGPRs, i.e. 3 workgroups per CU.
+    const int cb_group = (lane < 7) ? lane : (lane >= 56 && lane < 63) ? lane - 56 : -1;
     const bool odd = (lane & 1) != 0;
     float pp[12];
 #pragma unroll
@@ -158,13 +150,21 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
 
         // ---- carrier phase from the two sync words (softbits_kernel.cuh:88-137): sum c3[k]*conj(cb[k]) ----
         float pr = 0.0f, pi = 0.0f;
-#pragma unroll
-        for(int t = 0; t < kGroup; t++)
         {
-            pr = fmaf(acc[0][t].x, cbr[t], pr);
-            pr = fmaf(acc[0][t].y, cbi[t], pr);
-            pi = fmaf(acc[0][t].y, cbr[t], pi);
-            pi = fmaf(-acc[0][t].x, cbi[t], pi);
+            int g = cb_group < 0 ? 0 : cb_group;
+            asm volatile("" : "+v"(g));  // opaque per iteration: stops the compiler from hoisting the loads (and 12 VGPRs) out of the loop
+            const float2* __restrict__ cbp = a.st.cb42 + g * kGroup;
+            const float keep = cb_group < 0 ? 0.0f : 1.0f;
+#pragma unroll
+            for(int t = 0; t < kGroup; t++)
+            {
+                const float2 cbt = cbp[t];
+                const float cbr = cbt.x * keep, cbi = cbt.y * keep;
+                pr = fmaf(acc[0][t].x, cbr, pr);
+                pr = fmaf(acc[0][t].y, cbi, pr);
+                pi = fmaf(acc[0][t].y, cbr, pi);
+                pi = fmaf(-acc[0][t].x, cbi, pi);
+            }
         }
         const float sre = wave_sum(pr);
         const float sim = wave_sum(pi);
