@@ -20,27 +20,8 @@ HOST_SO = os.path.join(ROOT, "msk144cudecoder_amd", "libmsk144host.so")
 
 def _expected_lines(orc, stream, cfg, read_mode, quirk):
     """Oracle decode of every window + the host library's post-processing (the same C++ the CLI links)."""
-    H = C.CDLL(HOST_SO)
-    H.msk144host_table_new.restype = C.c_void_p
-    H.msk144host_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
-    table = H.msk144host_table_new()
-    o = orc.Oracle(threads=8, **cfg)
-    snr = orc.Snr()
-    out = []
-    for w in synth.windows_of(stream, read_mode):
-        cd = o.frontend_audio(w, 2) if read_mode == 1 else o.frontend_iq(w)
-        s = snr.process(cd)
-        items, _ = o.decode_window(cd)
-        acc = items[items["is_message_present"] == 1]
-        arr = (Accepted * max(len(acc), 1))()
-        for a, it in zip(arr, acc):
-            a.f0, a.num_avg, a.nbadsync, a.pattern_idx = float(it["f0"]), int(it["num_avg"]), int(it["nbadsync"]), int(it["pattern_idx"])
-            a.bits[:] = [int(b) for b in it["message"]]
-        buf = C.create_string_buffer(16384)
-        n = H.msk144host_postprocess(table, arr, len(acc), s, 1 if quirk else 0, buf, len(buf))
-        if n:
-            out += buf.value.decode().split("\n")
-    return [re.sub(r"date=\d{14}", "date=X", l) for l in out]
+    from oracle import oracle_cli
+    return oracle_cli.decode_stream(stream, cfg, read_mode, 2, quirk=quirk, threads=8)
 
 
 def _run(args, data):
@@ -124,3 +105,17 @@ def test_cli_multi_stream_equals_single_streams(tmp_path):
     for c in range(3):
         assert per_ch[c] == singles[c]
     assert err.count("Incomplete read error") == 3 and "Input streams: 3" in err
+
+
+def test_cli_s1_stream_light_config(orc):
+    """BASELINE configs[0]/[1] stand-in (demo/0001.wav is absent): the S1 functional stream at the README's
+    'optimal scan' options, HIP program vs the oracle-driven CPU decoder, line for line."""
+    stream, pings = synth.stream_s1(0, seconds=8.0, n_pings=4, span=40.0)
+    cfg = dict(center=1500.0, width=100.0, step=2.0, depth=3, nbadsync_threshold=1)
+    args = ["--search-width=100", "--scan-depth=3"]
+    rc, out, err = _run(args + ["--strict-decode"], stream.tobytes())
+    assert rc == 0, err
+    got = [re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]]
+    want = _expected_lines(orc, stream, cfg, 1, quirk=False)
+    assert got == want
+    assert "Left Boundary: 1450Hz" in err and "Right Boundary: 1550Hz" in err
