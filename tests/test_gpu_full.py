@@ -78,3 +78,29 @@ def test_1024_channel_batch_properties(orc, hip):
             d1.submit_audio(wins[2, ch])
             d1.decode()
             assert d1.dump_candidates(0).tobytes() == blob              # batch == single, bit for bit
+
+
+def test_fine_step_depth8_all_gated(orc, hip):
+    """Quarter-Hz grid, all 8 patterns, threshold 16 (every candidate is BP-decoded): F=401, 25 664 candidates."""
+    cfg = dict(center=1500.0, width=100.0, step=0.25, depth=8, nbadsync_threshold=16)
+    rng = np.random.default_rng(77)
+    msg = synth.random_message(rng)
+    x = synth.synth_audio(5184, [synth.Ping(msg, 2500, 3, 1500.0 + 17.37, 1.0, 2.2)], 1000.0, rng)
+    o = orc.Oracle(threads=16, **cfg)
+    cd = o.frontend_audio(x, 2)
+    items_o, idx_o = o.decode_window(cd)
+    with hip.HipDecoder(channels=1, **cfg) as d:
+        assert (d.F, d.D, d.K) == (401, 8, 25664)
+        d.submit_audio(x)
+        d.decode()
+        items_g = d.dump_candidates(0)
+        idx_g = d.dump_indexes(0)
+    assert np.array_equal(idx_g, np.arange(25664)) and np.array_equal(idx_o, idx_g)
+    assert np.array_equal(items_o["f0"].view(np.uint32), items_g["f0"].view(np.uint32))
+    rep = parity.compare_scan(o, cd, items_o, items_g)
+    assert rep["near_ties"] <= 26, rep
+    parity.compare_softbits(o, cd, items_o, items_g)
+    same = items_o["pos"] == items_g["pos"]
+    assert (items_o["is_message_present"][same] != items_g["is_message_present"][same]).sum() <= 2
+    assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
+    assert bytes(msg) in parity.decoded_messages(items_g)
