@@ -148,11 +148,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     // ---- 1. mix down by the hypothesis frequency (scan_kernel.cuh:45-69) ----
     const float f0 = -1.0f * a.st.freq[b];
     const float2* __restrict__ cdat = a.st.analytic + static_cast<size_t>(ch) * kWindowSamples;
+    float2 xin[kOutPerThread];  // all nine loads in flight before any arithmetic: one L2 latency per tile, not three
+#pragma unroll
+    for(int i = 0; i < kOutPerThread; i++) xin[i] = cdat[tid + i * kScanThreads];
 #pragma unroll
     for(int i = 0; i < kOutPerThread; i++)
     {
         const int n = tid + i * kScanThreads;
-        const float2 y = mix_sample(cdat[n], n, f0);
+        const float2 y = mix_sample(xin[i], n, f0);
         s_buf[n] = y;
         if(n < kWrapPad) s_buf[kWindowSamples + n] = y;
     }

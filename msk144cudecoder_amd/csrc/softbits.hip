@@ -84,11 +84,26 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
     // ---- mix (softbits_kernel.cuh:27-52) ----
     const float f0 = -1.0f * a.st.freq[b];
     const float2* __restrict__ cdat = a.st.analytic + static_cast<size_t>(ch) * kWindowSamples;
-    for(int n = tid; n < kWindowSamples; n += kSbThreads)
     {
-        const float2 y = mix_sample(cdat[n], n, f0);
-        s_x[n] = y;
-        if(n < kRunPad) s_x[kWindowSamples + n] = y;
+        constexpr int kPerThread = (kWindowSamples + kSbThreads - 1) / kSbThreads;  // 11 (10.125)
+        float2 xin[kPerThread];  // all loads in flight before any arithmetic
+#pragma unroll
+        for(int i = 0; i < kPerThread; i++)
+        {
+            const int n = tid + i * kSbThreads;
+            xin[i] = n < kWindowSamples ? cdat[n] : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for(int i = 0; i < kPerThread; i++)
+        {
+            const int n = tid + i * kSbThreads;
+            if(n < kWindowSamples)
+            {
+                const float2 y = mix_sample(xin[i], n, f0);
+                s_x[n] = y;
+                if(n < kRunPad) s_x[kWindowSamples + n] = y;
+            }
+        }
     }
     __syncthreads();
 
