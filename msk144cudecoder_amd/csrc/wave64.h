@@ -70,11 +70,13 @@ constexpr int kDppRowMirror = 0x140;
 // 16-lane row (quad xor 1, quad xor 2, half mirror, mirror), row_bcast:15 / row_bcast:31 fold the rows
 // into lane 63.  hipcc expands the builtin form into mov + nop + mov_dpp + canonicalise + max per step,
 // hence the asm; the 2 wait states a DPP read needs after a VALU write are inside the string (hipcc does
-// not insert hazard nops for asm statements).  NaN operands are ignored (v_max_f32 maxNum).
+// not insert hazard nops for asm statements); the leading s_nop 4 also covers the 5 wait states a DPP op
+// needs after a VALU write of EXEC (v_cmpx) that the compiler may have placed right before the statement.
+// NaN operands are ignored (v_max_f32 maxNum).
 __device__ __forceinline__ float wave_max_f32(float v)
 {
     float r;
-    asm volatile("s_nop 1\n\t"
+    asm volatile("s_nop 4\n\t"
                  "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\t"
                  "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
@@ -96,7 +98,7 @@ __device__ __forceinline__ float wave_max_f32(float v)
 __device__ __forceinline__ float oct_min_f32(float v)
 {
     float r;
-    asm volatile("s_nop 1\n\t"
+    asm volatile("s_nop 4\n\t"
                  "v_min_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\t"
                  "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
@@ -113,7 +115,7 @@ __device__ __forceinline__ float oct_min_f32(float v)
 __device__ __forceinline__ float row_sum_f32(float v)
 {
     float r;
-    asm volatile("s_nop 1\n\t"
+    asm volatile("s_nop 4\n\t"
                  "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\t"
                  "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
