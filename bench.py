@@ -6,10 +6,15 @@
 
 A "step" = one decode window (5184 samples) of every channel of the batch: BASELINE.json configs[2],
 1024 synthetic 12 ksps audio channels per MI355X (F=501 x D=6 x 8 = 24 048 candidates per window,
-24.6 M candidates per step and GPU).  Inputs are int16 windows already resident in HBM.  For N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank decodes its own 1024 channels - the
-path shards by channel with no data-path collective - and each step ends with one RCCL gather of the
-fixed-size decoded-record buffers to rank 0 ("scaling": "weak").
+24.6 M candidates per step and GPU).  Inputs are int16 windows already resident in HBM.
+
+N > 1: `python bench.py --gpus N` starts the N ranks ITSELF - the parent process never imports torch.cuda
+or touches HIP; it runs `python -m torch.distributed.run --nproc-per-node N bench.py ... --worker` as a
+child, relays rank 0's JSON line and exits with the child's status.  Launched by the driver through
+torch.distributed.run (WORLD_SIZE set) it is a worker directly.  Every rank decodes its own 1024 channels
+(the path shards by channel, no data-path collective) and each step ends with ONE exchange: an RCCL
+gather of the fixed-size decoded-record buffers (global channel ids, (n, total) trailer) to rank 0, which
+validates total <= capacity for every rank and step ("scaling": "weak").
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel with SURVEY.md 8(d)'s algorithmic
 634 B/candidate against the 8 TB/s HBM peak; the path is VALU/LDS-bound (10^3..10^6 flop per
@@ -20,8 +25,11 @@ frequency hypotheses) on a bounded sample of the same windows - a reported basel
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,7 +43,20 @@ CHANNELS_PER_GPU = 1024
 WINDOWS_PER_CHANNEL = 4          # distinct consecutive windows staged per channel, cycled by the steps
 B_ALG_PER_CANDIDATE = 634.0      # one 632-byte result record written + window share read
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-GATHER_CAP = 8192                # decoded records gathered per rank and step (fixed-size buffer)
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMD-32, one wave64 VALU op per 2 cycles at 2.4 GHz
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "counters.json")
+
+
+def kernel_source_sha() -> str:
+    """Hash of the kernel sources; profiles/counters.json records the one it was collected on, so stale
+    static counters are never mixed with live timings."""
+    csrc = os.path.join(ROOT, "msk144cudecoder_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_inputs(rank: int, channels: int):
@@ -70,6 +91,54 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+class HipBackend:
+    """The product path: libmsk144hip.so through its C ABI (ctypes), inputs resident in HBM."""
+    name = "hip"
+    dist_backend = "nccl"
+    data = "synthetic"
+
+    def __init__(self, rank: int, local_rank: int, channels: int, channel_base: int, mode: str = "staged"):
+        import torch
+        from msk144cudecoder_amd.hipdecoder import RESULT_DTYPE, T_NAMES, HipDecoder  # fails loudly without the HIP library
+        self.torch = torch
+        self.T_NAMES = T_NAMES
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        self.wins_host, self.truth = make_inputs(rank, channels)
+        self.wins_dev = torch.from_numpy(self.wins_host).cuda(local_rank)   # inputs resident in HBM before timing
+        self.dec = HipDecoder(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, read_mode=1,
+                              analytic_method=2, channels=channels, device=local_rank, max_results=1 << 20)
+        self.dec.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.dec.set_channel_base(channel_base)
+        self.channel_base = channel_base
+        self.F, self.D, self.K = self.dec.F, self.dec.D, self.dec.K
+        self.cand_per_step = channels * self.dec.K
+        rec_ptr, cnt_ptr = self.dec.results_device()
+        self.rec_view = torch.as_tensor(_DevView(rec_ptr, (1 << 20) * RESULT_DTYPE.itemsize), device=self.device)
+        self.cnt_view = torch.as_tensor(_DevView(cnt_ptr, 4), device=self.device).view(torch.int32)
+
+    def step(self, i: int):
+        w = self.wins_dev[i % WINDOWS_PER_CHANNEL]
+        self.dec.submit_audio_device(w.data_ptr())
+        self.dec.decode()
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+
+    def start_profiling(self):
+        self.dec.set_profiling(True)
+        self.dec.stage_times(reset=True)
+
+    def stage_times(self):
+        return self.dec.stage_times()
+
+    def results(self):
+        return self.dec.results()
+
+    def close(self):
+        self.dec.close()
+
+
 def cpu_baseline(windows: np.ndarray, budget_s: float = 12.0):
     """Oracle ('port' of the reference algorithm) on the host cores, bounded sample of the same workload."""
     from oracle import oracle as orc  # test infrastructure: used here only as the timed CPU baseline
@@ -89,69 +158,102 @@ def cpu_baseline(windows: np.ndarray, budget_s: float = 12.0):
             "sample": f"{done} window(s) of channel(s) 0..{done - 1}, step 0 (of {windows.shape[1]} channels), {el:.1f} s; exhaustive reference algorithm, not WSJT-X msk144spd"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=CHANNELS_PER_GPU, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--launcher", action="store_true", help="go through the N-rank launcher even for --gpus 1 (exercises the RCCL gather path)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend-module", default=None, help="TEST HOOK: module providing Backend (e.g. tests/stub_backend.py on gloo); the line is then labelled as such")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv) -> int:
+    """Parent of an N-rank run.  Touches no GPU API: it only starts torch.distributed.run as a CHILD process
+    (never exec: a process that has initialised the GPU must not be replaced, and this one has not even
+    imported torch) and relays rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    passed = [a for a in argv if a != "--launcher"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + passed + ["--worker"]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def run_worker(args) -> int:
+    import importlib
 
     import torch
     import torch.distributed as dist
 
+    from msk144cudecoder_amd import sharding
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun the RCCL path runs even with one rank
+    distributed = "WORLD_SIZE" in os.environ       # under torch.distributed.run the gather path runs even with one rank
+    if distributed and args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled run", file=sys.stderr)
+        return 2
+
+    Backend = importlib.import_module(args.backend_module).Backend if args.backend_module else HipBackend
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.gpus != world:
-        if rank == 0 and distributed:
-            print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from msk144cudecoder_amd.hipdecoder import RESULT_DTYPE, T_NAMES, HipDecoder  # fails loudly without the HIP library
+        if Backend.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(Backend.dist_backend)
 
     channels = args.channels
-    wins_host, truth = make_inputs(rank, channels)
-    wins_dev = torch.from_numpy(wins_host).cuda(local_rank)           # inputs resident in HBM before timing
+    channel_base, _ = sharding.shard_channels(channels * world, rank, world)   # rank r owns global channels [r*C, (r+1)*C)
+    be = Backend(rank, local_rank, channels, channel_base)
+    cand_per_step = be.cand_per_step
 
-    dec = HipDecoder(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, read_mode=1, analytic_method=2,
-                     channels=channels, device=local_rank, max_results=1 << 20)
-    dec.set_stream(torch.cuda.current_stream().cuda_stream)
-    cand_per_step = channels * dec.K
-
-    rec_ptr, cnt_ptr = dec.results_device()
-    rec_view = torch.as_tensor(_DevView(rec_ptr, GATHER_CAP * RESULT_DTYPE.itemsize), device=f"cuda:{local_rank}")
-    cnt_view = torch.as_tensor(_DevView(cnt_ptr, 4), device=f"cuda:{local_rank}")
-    send = torch.empty(GATHER_CAP * RESULT_DTYPE.itemsize + 4, dtype=torch.uint8, device=f"cuda:{local_rank}")
-    gathered = [torch.empty_like(send) for _ in range(world)] if (distributed and rank == 0) else None
+    gather = None
+    if distributed:
+        cap = sharding.gather_capacity(channels)
+        gather = sharding.RecordGather(cap, be.device, world, rank)
 
     def step(i):
-        w = wins_dev[i % WINDOWS_PER_CHANNEL]
-        dec.submit_audio_device(w.data_ptr())
-        dec.decode()
-        if distributed:
+        be.step(i)
+        if gather is not None:
             # the path's only exchange: fixed-size decoded-record buffers -> rank 0 (RCCL over xGMI)
-            send[:-4].copy_(rec_view, non_blocking=True)
-            send[-4:].copy_(cnt_view, non_blocking=True)
-            dist.gather(send, gathered, dst=0)
+            gather.step(be.rec_view, be.cnt_view)
 
     def fence():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        be.fence()
 
     for i in range(args.warmup):
         step(i)
     fence()
-    dec.set_profiling(True)
-    dec.stage_times(reset=True)
+    be.start_profiling()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -160,72 +262,109 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=be.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    stage = dec.stage_times()
-    last = dec.results()
+    stage = be.stage_times()
+    last = be.results()
     # Payloads that are not the channel's transmitted message.  The reference algorithm accepts on CRC-13
     # + < 18 hard errors, so at 1.6e7 BP attempts per step a few false positives are expected; they are
     # the oracle's too (tests/test_gpu_full.py), not decoder errors.
-    wrong = sum(1 for r in last if truth.get(int(r["channel"])) != bytes(r["message"]))
+    wrong = sum(1 for r in last if be.truth.get(int(r["channel"]) - channel_base) != bytes(r["message"]))
     chans_decoded = len({int(r["channel"]) for r in last})
 
-    if rank == 0:
+    rc = 0
+    gathered_records = None
+    if gather is not None:
+        try:
+            per_rank = gather.finish()                      # raises OverflowError if any rank exceeded the capacity
+            if rank == 0:
+                gathered_records = int(sum(len(r) for r in per_rank))
+                for r, rec in enumerate(per_rank):
+                    lo, cnt = sharding.shard_channels(channels * world, r, world)
+                    if len(rec) and not ((rec["channel"] >= lo) & (rec["channel"] < lo + cnt)).all():
+                        raise AssertionError(f"rank {r}: gathered channel ids outside its shard [{lo}, {lo + cnt})")
+                if not np.array_equal(per_rank[0], last[:len(per_rank[0])]) or len(per_rank[0]) != len(last):
+                    raise AssertionError("rank 0's gathered records differ from its own result list")
+        except (OverflowError, AssertionError) as e:
+            print(f"bench.py: gather validation failed: {e}", file=sys.stderr)
+            rc = 3
+
+    if rank == 0 and rc == 0:
+        T_NAMES = be.T_NAMES
         ms_per_step = elapsed / args.steps * 1e3
         value = world * cand_per_step * args.steps / elapsed
         dom = max((n for n in T_NAMES), key=lambda n: stage[n][0])
         dom_ms = stage[dom][0]
         achieved = B_ALG_PER_CANDIDATE * cand_per_step / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        # Static PMC counters (separate rocprofv3 --pmc passes, committed under profiles/): used only when they were
+        # collected on exactly these kernel sources and this workload; labelled with their origin.
+        traffic, valu, static = None, None, None
+        if os.path.exists(COUNTERS_FILE) and channels == CHANNELS_PER_GPU and Backend is HipBackend:
             try:
-                traffic = json.load(open(tfile)).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # The bound that actually applies: VALU instruction issue.  Instruction counts per launch come from the
-        # committed SQ counter pass of this same command (profiles/r01_sq_counters.json); the rate uses the
-        # HIP-event time of THIS run.  Ceiling ~8e11 wave-instr/s (tools/ubench/valu_rates.hip).
-        valu = None
-        cfile = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
-        if os.path.exists(cfile) and channels == CHANNELS_PER_GPU:
-            try:
-                sq = json.load(open(cfile))
-                valu = {"unit": "wave-instr/s", "ceiling": 8.0e11, "source": "profiles/r01_sq_counters.json (SQ_INSTS_VALU) / stage_ms"}
-                for k in ("scan", "softbits", "ldpc"):
-                    if stage[k][0] > 0:
-                        rate = sq[k + "_kernel"]["SQ_INSTS_VALU"] / (stage[k][0] * 1e-3)
-                        valu[k + "_kernel"] = {"achieved": rate, "frac": rate / 8.0e11}
-            except Exception:
-                valu = None
+                cj = json.load(open(COUNTERS_FILE))
+                if cj.get("kernel_source_sha") == kernel_source_sha():
+                    static = f"profiles/counters.json@{cj.get('commit', '?')} (kernel_source_sha {cj['kernel_source_sha']})"
+                    traffic = cj.get("kernels", {}).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
+                    valu = {"unit": "wave-instr/s", "peak": VALU_PEAK_WAVE_INSTR,
+                            "peak_note": "256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 VALU op (MI355X_MICROARCH.md); transcendentals and "
+                                         "v_pk_* cost more than one slot, see profiles/r02_valu_issue_microbench.txt",
+                            "static": static}
+                    for k in ("scan", "softbits", "ldpc"):
+                        n_valu = cj.get("kernels", {}).get(k + "_kernel", {}).get("SQ_INSTS_VALU")
+                        if n_valu and stage[k][0] > 0:
+                            rate = n_valu / (stage[k][0] * 1e-3)
+                            valu[k + "_kernel"] = {"achieved": rate, "frac": rate / VALU_PEAK_WAVE_INSTR}
+                else:
+                    static = "profiles/counters.json is stale for these kernel sources: traffic/valu_issue omitted"
+            except Exception as e:  # noqa: BLE001
+                static = f"profiles/counters.json unreadable: {e}"
         out = {
             "metric": "candidate decodes/sec (scan+softbits+LDPC), width=500 step=1 depth=6",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": Backend.data,
             "config": {"workload": f"BASELINE configs[2]: {channels} synthetic 12 ksps int16 audio channels per GPU, one 5184-sample window per "
-                                   f"channel per step, width=500 step=1 depth=6 nbadsync-threshold=3 (F={dec.F}, D={dec.D}, {dec.K} candidates/window)",
+                                   f"channel per step, width=500 step=1 depth=6 nbadsync-threshold=3 (F={be.F}, D={be.D}, {be.K} candidates/window)",
                        "channels_per_gpu": channels, "candidates_per_step_per_gpu": cand_per_step, "parallelism": f"channel-shard x{world}",
-                       "analytic_method": 2, "real_time_channels": value / dec.K / (12000.0 / 2592.0)},
+                       "analytic_method": 2, "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
+                       "real_time_channels": value / be.K / (12000.0 / 2592.0)},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_step, "avg_launch_ms": dom_ms,
                          "note": "path is VALU/LDS-bound (SURVEY.md 8d); HBM fraction reported as measured"},
             "valu_issue": valu,
             "stage_ms": {n: round(stage[n][0], 4) for n in T_NAMES},
             "decodes_last_step": int(len(last)), "channels_decoded_last_step": chans_decoded, "crc13_false_positives_last_step": wrong,
         }
-        if not distributed and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wins_host)
+        if gather is not None:
+            out["gather"] = {"records_last_step": gathered_records, "capacity_per_rank": gather.cap, "bytes_per_rank": int(gather.send.numel()),
+                             "peak_records_per_rank": [int(x) for x in gather.max_total.cpu().numpy()], "backend": Backend.dist_backend}
+        if not distributed and not args.no_cpu_baseline and Backend is HipBackend:
+            out["cpu_baseline"] = cpu_baseline(be.wins_host)
         print(json.dumps(out), flush=True)
 
-    dec.close()
+    be.close()
     if distributed:
+        flag = torch.tensor([rc], dtype=torch.int32, device=be.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        rc = int(flag.item())
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and not args.worker and (args.gpus > 1 or args.launcher):
+        return launch_ranks(args, argv)
+    return run_worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

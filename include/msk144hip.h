@@ -158,6 +158,10 @@ int msk144_result_count(msk144_handle* h, int32_t* n);
 /* device-side list for callers that gather on the GPU (RCCL): records + count stay valid until the
  * next decode */
 int msk144_results_device(msk144_handle* h, const msk144_result** d_records, const int32_t** d_count);
+/* Multi-GPU sharding (no reference counterpart: the reference decodes one stream on one GPU, main.cu:115):
+ * msk144_result.channel = base + local channel, so that the records of a rank that owns channels
+ * [base, base+channels) carry global channel ids when they are gathered.  Default 0. */
+int msk144_set_channel_base(msk144_handle* h, int32_t base);
 
 int msk144_segment_power(msk144_handle* h, float* out /*[channels][8]*/);
 

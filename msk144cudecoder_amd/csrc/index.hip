@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kIdxThreads) void collect_scatter_kernel(const Devi
             const int b = k / per_freq;
             const int p = (k - b * per_freq) / kSlotsPerPattern;
             msk144_result r;
-            r.channel = ch;
+            r.channel = st.channel_base + ch;
             r.item = k;
             r.f0 = st.freq[b];
             r.pattern_idx = p;

@@ -548,6 +548,14 @@ int msk144_results_device(msk144_handle* h, const msk144_result** d_records, con
     return MSK144_OK;
 }
 
+int msk144_set_channel_base(msk144_handle* h, int32_t base)
+{
+    if(!h) return MSK144_EINVAL;
+    if(base < 0) return fail(h, MSK144_EINVAL, "channel base must be >= 0");
+    h->st.channel_base = base;  // kernel argument by value: takes effect at the next decode
+    return MSK144_OK;
+}
+
 int msk144_segment_power(msk144_handle* h, float* out)
 {
     if(!h || !out) return fail(h, MSK144_EINVAL, "null argument");

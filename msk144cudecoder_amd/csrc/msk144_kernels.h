@@ -29,6 +29,7 @@ struct DeviceStore
     int32_t K;                // items per channel = F*D*8
     int32_t nbadsync_threshold;
     int32_t max_results;
+    int32_t channel_base;     // added to the channel number in result records (multi-GPU sharding)
 
     const float* freq;        // [F] Hz, host-computed as msk_context.cuh:135
     const float2* cb42;       // [42] sync template (re, im), for kernels that index it per lane

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "msk144_default_params", "msk144_create", "msk144_destroy", "msk144_last_error", "msk144_geometry", "msk144_frequency",
     "msk144_set_stream", "msk144_submit_audio", "msk144_submit_iq", "msk144_submit_audio_device", "msk144_submit_iq_device",
     "msk144_submit_analytic", "msk144_decode", "msk144_decode_stages", "msk144_synchronize", "msk144_results",
-    "msk144_result_count", "msk144_results_device", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
+    "msk144_result_count", "msk144_results_device", "msk144_set_channel_base", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
 )
 
@@ -92,6 +92,7 @@ def load_library(path: Optional[str] = None):
     L.msk144_results.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.msk144_result_count.argtypes = [vp, C.POINTER(i32)]
     L.msk144_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.msk144_set_channel_base.argtypes = [vp, i32]
     L.msk144_segment_power.argtypes = [vp, vp]
     L.msk144_dump_analytic.argtypes = [vp, i32, vp]
     L.msk144_dump_candidates.argtypes = [vp, i32, vp]
@@ -204,6 +205,10 @@ class HipDecoder:
         rec, cnt = C.c_void_p(), C.c_void_p()
         self._chk(self.L.msk144_results_device(self.h, C.byref(rec), C.byref(cnt)))
         return rec.value, cnt.value
+
+    def set_channel_base(self, base: int):
+        """Result records carry channel = base + local channel (global ids for the multi-GPU gather)."""
+        self._chk(self.L.msk144_set_channel_base(self.h, base))
 
     def segment_power(self) -> np.ndarray:
         out = np.empty((self.channels, 8), dtype=np.float32)

@@ -13,7 +13,7 @@ import numpy as np
 
 from .hipdecoder import RESULT_DTYPE
 
-__all__ = ["shard_channels", "pack_records", "unpack_records", "gather_records"]
+__all__ = ["shard_channels", "pack_records", "unpack_records", "gather_records", "gather_capacity", "RecordGather"]
 
 
 def shard_channels(n_channels: int, rank: int, world: int) -> Tuple[int, int]:
@@ -71,3 +71,57 @@ def gather_records(records: np.ndarray, cap: int, channel_offset: int, device: O
             raise OverflowError(f"a rank decoded {total} records, more than the gather capacity {cap}")
         out.append(rec)
     return out
+
+
+def gather_capacity(channels: int) -> int:
+    """Records gathered per rank and step: 32 per channel (a ping is decoded by several of its candidates:
+    the 1024-channel bench sees ~7 records per channel and step), at least 1024."""
+    return max(1024, 32 * int(channels))
+
+
+class RecordGather:
+    """The per-step exchange on DEVICE buffers: every rank sends uint8[cap*52 + 8] = records | n | total to
+    rank 0, the same layout as pack_records (records already carry global channel ids:
+    msk144_set_channel_base).  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in the
+    CPU tests).  Nothing is read back on the host inside step(); rank 0 keeps a running maximum of every
+    rank's `total` on the device and finish() validates it against the capacity."""
+
+    def __init__(self, cap: int, device, world: int, rank: int):
+        import torch
+        self.cap, self.world, self.rank = int(cap), int(world), int(rank)
+        self.nbytes = self.cap * RESULT_DTYPE.itemsize
+        self.send = torch.zeros(self.nbytes + 8, dtype=torch.uint8, device=device)
+        self._trailer = self.send[self.nbytes:].view(torch.int32)                # [n, total]
+        self.recv = [torch.zeros_like(self.send) for _ in range(world)] if rank == 0 else None
+        self._recv_trailers = [t[self.nbytes:].view(torch.int32) for t in self.recv] if rank == 0 else None
+        self.max_total = torch.zeros(world, dtype=torch.int32, device=device) if rank == 0 else None
+        self.steps = 0
+
+    def step(self, rec_bytes, count_i32):
+        """rec_bytes: uint8 view of the decoder's device record list (>= cap*52 bytes); count_i32: int32[1]
+        view of its device-side record count."""
+        import torch
+        import torch.distributed as dist
+        self.send[:self.nbytes].copy_(rec_bytes[:self.nbytes], non_blocking=True)
+        self._trailer[1:2].copy_(count_i32, non_blocking=True)
+        torch.clamp(count_i32, max=self.cap, out=self._trailer[0:1])
+        dist.gather(self.send, self.recv, dst=0)
+        if self.rank == 0:
+            tot = torch.stack([t[1] for t in self._recv_trailers])
+            torch.maximum(self.max_total, tot, out=self.max_total)
+        self.steps += 1
+
+    def finish(self) -> Optional[List[np.ndarray]]:
+        """Rank 0: per-rank record arrays of the last step; raises OverflowError if any rank ever produced
+        more records than the capacity.  Other ranks: None."""
+        if self.rank != 0:
+            return None
+        worst = self.max_total.cpu().numpy()
+        if (worst > self.cap).any():
+            raise OverflowError(f"decoded records per rank and step peaked at {worst.tolist()}, gather capacity is {self.cap}")
+        out = []
+        for t in self.recv:
+            rec, total = unpack_records(t.cpu().numpy())
+            assert total == len(rec)
+            out.append(rec)
+        return out

@@ -1,0 +1,55 @@
+"""TEST-ONLY stand-in for bench.HipBackend: lets the N-rank launcher, the gloo process group and the device-buffer
+gather of bench.py run on a machine without a GPU.  It decodes nothing: every step it publishes a fixed, rank-dependent
+record list in the same device-side layout the HIP decoder exposes (records | int32 count).  bench.py labels any line
+produced through it ("backend": "stub", "data": "stub (no decoding, test only)")."""
+import numpy as np
+import torch
+
+from msk144cudecoder_amd.hipdecoder import RESULT_DTYPE, T_NAMES
+
+
+class Backend:
+    name = "stub"
+    dist_backend = "gloo"
+    data = "stub (no decoding, test only)"
+
+    def __init__(self, rank, local_rank, channels, channel_base, mode="staged"):
+        self.T_NAMES = T_NAMES
+        self.device = torch.device("cpu")
+        self.F, self.D, self.K = 3, 2, 48
+        self.cand_per_step = channels * self.K
+        self.channel_base = channel_base
+        self.truth = {}
+        self.wins_host = np.zeros((1, channels, 5184), dtype=np.int16)
+        n = min(channels, 5 + rank)
+        rec = np.zeros(n, dtype=RESULT_DTYPE)
+        rec["channel"] = channel_base + np.arange(n)
+        rec["item"] = 1000 * rank + np.arange(n)
+        rec["message"][:, 0] = 0xA0 + rank
+        self._rec = rec
+        buf = np.zeros(max(channels * 32, 1024) * RESULT_DTYPE.itemsize, dtype=np.uint8)
+        buf[:rec.nbytes] = rec.view(np.uint8)
+        self.rec_view = torch.from_numpy(buf)
+        # MSK144_STUB_OVERFLOW: rank 1 claims more records than any capacity (tests the overflow check)
+        import os
+        claimed = 10 ** 6 if (os.environ.get("MSK144_STUB_OVERFLOW") and rank == 1) else n
+        self.cnt_view = torch.tensor([claimed], dtype=torch.int32)
+        self.steps = 0
+
+    def step(self, i):
+        self.steps += 1
+
+    def fence(self):
+        pass
+
+    def start_profiling(self):
+        pass
+
+    def stage_times(self):
+        return {n: (1.0 if n == "ldpc" else 0.5, self.steps) for n in T_NAMES}
+
+    def results(self):
+        return self._rec.copy()
+
+    def close(self):
+        pass

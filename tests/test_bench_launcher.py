@@ -1,0 +1,54 @@
+"""bench.py --gpus N must start N ranks by itself (the driver runs `python bench.py --gpus N`), run the per-step record
+gather through msk144cudecoder_amd.sharding and report n_gpus = N.  Exercised here on the CPU: gloo + tests/stub_backend."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--channels", "8",
+                           "--backend-module", "stub_backend"] + extra, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+def test_gpus2_self_launch_reports_two_ranks():
+    p = _run(["--gpus", "2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["backend"] == "stub" and out["data"].startswith("stub")      # never mistaken for a measurement
+    assert out["config"]["launch"] == "torch.distributed.run"
+    g = out["gather"]
+    assert g["backend"] == "gloo" and g["records_last_step"] == 5 + 6                   # rank 0: 5 records, rank 1: 6
+    assert g["peak_records_per_rank"] == [5, 6] and g["capacity_per_rank"] >= 1024
+    assert out["value"] > 0 and out["steps"] == 3
+
+
+def test_gpus1_through_launcher_matches_contract():
+    p = _run(["--gpus", "1", "--launcher"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["gather"]["records_last_step"] == 5
+
+
+def test_world_size_mismatch_is_refused():
+    """Under torch.distributed.run with WORLD_SIZE != --gpus the worker must refuse rather than print a mislabelled line."""
+    p = _run(["--gpus", "2"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"})
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_gather_overflow_fails_the_run():
+    """A rank that decodes more records than the gather capacity must fail the run, not truncate silently."""
+    p = _run(["--gpus", "2"], env_extra={"MSK144_STUB_OVERFLOW": "1"})
+    assert p.returncode != 0
+    assert "gather" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
