@@ -27,7 +27,7 @@ SOURCES = [
     ("ldpc.hip", []),
     ("msk144_api.cpp", ["-x", "hip", "-ffp-contract=off"]),
 ]
-HEADERS = ["msk144_protocol.h", "msk144_kernels.h", "wave64.h", os.path.join("..", "..", "include", "msk144hip.h")]
+HEADERS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "msk144hip.h")]
 
 
 def _hipcc() -> str:

@@ -75,7 +75,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 // the scaled quotient.  The first two pieces (x/0.83 and (z-0.4064)/0.322) meet exactly at the 0.664
 // breakpoint and the slope increases there, so that branch is a max(); the upper breakpoints, where the
 // reference's function jumps, stay explicit selects.
-__device__ __forceinline__ float two_platanh_scaled(float x)
+__device__ __forceinline__ float two_platanh_scaled_full(float x)
 {
     const float z = __builtin_fabsf(x);
     float c = 0.4064f, r = kLog2e * 2.0f / 0.322f;
@@ -91,6 +91,33 @@ __device__ __forceinline__ float two_platanh_scaled(float x)
     }
     float v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), (z - c) * r);
     if(z > 0.9998f) v = kLog2e * 14.0f;
+    return __builtin_copysignf(v, x);
+}
+
+// Same function, priced for what BP actually feeds it: a leave-one-out product of 9-10 tanh values exceeds
+// the 0.9217 breakpoint on ~0.1 % of the edges of a noise codeword (~6 % of the 64-lane edge instructions have
+// such a lane), so the two lower pieces (one max, no selects) run unconditionally and the three upper pieces
+// sit behind a wave-uniform branch.  Bit-identical to two_platanh_scaled_full for every input.
+__device__ __forceinline__ float two_platanh_scaled(float x)
+{
+    const float z = __builtin_fabsf(x);
+    float v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), (z - 0.4064f) * (kLog2e * 2.0f / 0.322f));
+    if(__builtin_expect(__builtin_amdgcn_ballot_w64(z > 0.9217f) != 0ull, 0))
+    {
+        float c = 0.4064f, r = kLog2e * 2.0f / 0.322f;
+        if(z > 0.9217f)
+        {
+            c = 0.8378f;
+            r = kLog2e * 2.0f / 0.0524f;
+        }
+        if(z > 0.9951f)
+        {
+            c = 0.9914f;
+            r = kLog2e * 2.0f / 0.0012f;
+        }
+        v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), (z - c) * r);
+        if(z > 0.9998f) v = kLog2e * 14.0f;
+    }
     return __builtin_copysignf(v, x);
 }
 
@@ -234,11 +261,17 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             }
             __builtin_amdgcn_wave_barrier();
 
-            // check -> bit messages
+            // check -> bit messages: all six products are read before the first (branchy) platanh so that the LDS
+            // latencies overlap
+            float prod[2][kEdgesPerBit];
 #pragma unroll
             for(int h = 0; h < 2; h++)
 #pragma unroll
-                for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh_scaled(T[e_addr[h][k]]);
+                for(int k = 0; k < kEdgesPerBit; k++) prod[h][k] = T[e_addr[h][k]];
+#pragma unroll
+            for(int h = 0; h < 2; h++)
+#pragma unroll
+                for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh_scaled(prod[h][k]);
             __builtin_amdgcn_wave_barrier();
             // restore the constant slot the column pass overwrote
             if(lane < kChecks && !my_full) T[(kMaxCheckDegree - 1) * kTStride + lane] = 1.0f;

@@ -4,6 +4,7 @@
 #include "../../include/msk144hip.h"
 
 #include "msk144_kernels.h"
+#include "msk144_tables.h"
 
 #include <hip/hip_runtime.h>
 
@@ -73,61 +74,6 @@ int fail(msk144_handle* h, int code, const std::string& msg)
         hipError_t e_ = (expr);                                                                            \
         if(e_ != hipSuccess) return fail(h, MSK144_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while(0)
-
-const float kPiF = 3.14159265358979323846f;
-
-// msk_context.cuh:137-196
-void build_template(SyncTemplate& t)
-{
-    float pp[12];
-    for(int i = 0; i < 12; i++)
-    {
-        float angle = i * kPiF / 12.0f;
-        pp[i] = sinf(angle);
-        t.pp[i] = pp[i];
-    }
-    const int* s8 = kSync8Pm;
-    float cbi[42], cbq[42];
-    for(int i = 0; i < 6; i++) cbq[0 + i] = pp[6 + i] * s8[0];
-    for(int i = 0; i < 12; i++) cbq[6 + i] = pp[i] * s8[2];
-    for(int i = 0; i < 12; i++) cbq[18 + i] = pp[i] * s8[4];
-    for(int i = 0; i < 12; i++) cbq[30 + i] = pp[i] * s8[6];
-    for(int i = 0; i < 12; i++) cbi[0 + i] = pp[i] * s8[1];
-    for(int i = 0; i < 12; i++) cbi[12 + i] = pp[i] * s8[3];
-    for(int i = 0; i < 12; i++) cbi[24 + i] = pp[i] * s8[5];
-    for(int i = 0; i < 6; i++) cbi[36 + i] = pp[i] * s8[7];
-    for(int i = 0; i < 42; i++)
-    {
-        t.re[i] = cbi[i];
-        t.im[i] = cbq[i];
-    }
-}
-
-// analytic_fft.cu:32-57
-void build_fft_mask(std::vector<float>& h)
-{
-    const int nfft = kFftSize;
-    const int nh = nfft / 2;
-    h.assign(nh, 0.0f);
-    const float df = 12000.0f / nfft;
-    const float pi = kPiF;
-    const float t = 1.0f / 2000.0f;
-    const float beta = 0.1f;
-    for(int i = 0; i < nh; i++)
-    {
-        float ff = i * df;
-        float f = ff - 1500.0f;
-        h[i] = 1.0f;
-        if(fabsf(f) > (1 - beta) / (2 * t) && fabsf(f) <= (1 + beta) / (2 * t))
-        {
-            h[i] = h[i] * 0.5f * (1.0f + static_cast<float>(cos((pi * t / beta) * (fabsf(f) - (1 - beta) / (2 * t)))));
-        }
-        else if(fabsf(f) > (1 + beta) / (2 * t))
-        {
-            h[i] = 0;
-        }
-    }
-}
 
 template<typename T>
 int dev_alloc(msk144_handle* h, T** p, size_t count)
@@ -280,12 +226,8 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
         return bail(MSK144_EHIP);
     }
 
-    // frequency grid (msk_context.cuh:95-107,135)
-    const int half_len = grid_half_len(params->width_hz, params->step_hz);
-    const int F = half_len * 2 + 1;
-    const float if1 = -1 * half_len * params->step_hz;
-    h->freq_host.resize(F);
-    for(int b = 0; b < F; b++) h->freq_host[b] = params->center_hz + if1 + static_cast<int>(b) * params->step_hz;
+    h->freq_host = frequency_grid(params->center_hz, params->width_hz, params->step_hz);
+    const int F = static_cast<int>(h->freq_host.size());
 
     DeviceStore& st = h->st;
     st.channels = params->channels;
@@ -299,7 +241,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     st.max_results = static_cast<int32_t>(maxr);
     h->params.max_results = st.max_results;
 
-    build_template(h->tpl);
+    sync_template(h->tpl.re, h->tpl.im, h->tpl.pp);
 
     if(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
     {
@@ -356,8 +298,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
 
     if(ok && params->read_mode == 1 && params->analytic_method == 1)
     {
-        std::vector<float> mask;
-        build_fft_mask(mask);
+        const std::vector<float> mask = fft_band_mask();
         std::vector<float2> tw(kFftSize / 2);
         for(int j = 0; j < kFftSize / 2; j++)
         {

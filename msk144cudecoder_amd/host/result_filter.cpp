@@ -1,8 +1,10 @@
 #include "result_filter.h"
 
+#include <algorithm>
 #include <ctime>
 #include <iomanip>
 #include <sstream>
+#include <tuple>
 
 namespace msk144host
 {
@@ -43,22 +45,24 @@ void ResultFilter::put(int snr, float f0, int num_avg, int nbadsync, int pattern
     r.pattern_idx = pattern_idx;
     r.text = text;
     r.stamp = std::chrono::system_clock::now();
-    auto it = best_.find(text);
-    if(it == best_.end())
-    {
-        best_.emplace(text, std::move(r));
-        return;
-    }
-    const FilteredResult& cur = it->second;
-    const bool better = (r.num_avg < cur.num_avg) || (r.num_avg == cur.num_avg && r.nbadsync < cur.nbadsync);
-    if(better) it->second = std::move(r);
+    by_text_[text].push_back(std::move(r));  // arrival (item) order is kept inside a text group
 }
 
 std::vector<FilteredResult> ResultFilter::end_window() const
 {
     std::vector<FilteredResult> out;
-    out.reserve(best_.size());
-    for(const auto& kv : best_) out.push_back(kv.second);  // std::map iterates in lexicographic key order
+    out.reserve(by_text_.size());
+    for(const auto& kv : by_text_)  // std::map iterates in lexicographic key order, like the reference's std::set
+    {
+        // The winner of a text group is whatever std::sort leaves in front (result_filter.cpp:61-72).  Exact ties
+        // (same num_avg and nbadsync - routine: one ping is decoded by dozens of candidates) are broken by the sort
+        // algorithm itself, so the same call on the same sequence is made here: built against the same standard
+        // library this picks the same item - and prints the same f0/pattern_idx - as the reference binary.
+        std::vector<FilteredResult> group = kv.second;
+        std::sort(group.begin(), group.end(),
+                  [](const FilteredResult& a, const FilteredResult& b) { return std::tie(a.num_avg, a.nbadsync) < std::tie(b.num_avg, b.nbadsync); });
+        out.push_back(group.front());
+    }
     return out;
 }
 

@@ -1,7 +1,9 @@
 // Per-window de-duplication of decoded texts (behaviour of ResultFilter, result_filter.cpp:43-74):
 // one line per distinct text, in lexicographic order of the text; among candidates with the same text
-// the one with the lowest num_avg wins, then the lowest nbadsync.  The reference sorts with std::sort
-// (order of exact ties unspecified); here the earliest candidate wins a tie, deterministically.
+// the one with the lowest num_avg wins, then the lowest nbadsync.  Exact ties are common (one ping is decoded
+// by many candidates) and the reference leaves them to std::sort; this class makes the same std::sort call on
+// the same sequence, so a build against the same standard library prints the same candidate.  Checked against
+// the reference's own compiled result_filter.cpp (oracle/_ref, tests/test_ref_host.py).
 #pragma once
 
 #include <chrono>
@@ -29,12 +31,12 @@ struct FilteredResult
 class ResultFilter
 {
 public:
-    void begin_window() { best_.clear(); }
+    void begin_window() { by_text_.clear(); }
     void put(int snr, float f0, int num_avg, int nbadsync, int pattern_idx, const std::string& text);
     std::vector<FilteredResult> end_window() const;
 
 private:
-    std::map<std::string, FilteredResult> best_;
+    std::map<std::string, std::vector<FilteredResult>> by_text_;
 };
 
 }  // namespace msk144host
