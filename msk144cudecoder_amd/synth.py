@@ -24,7 +24,7 @@ from .protocol import (CHECK_BITS, CRC13_POLY, FRAME_SAMPLES, SAMPLE_RATE, SYNC8
 
 __all__ = [
     "crc13_bits", "ldpc_parity_matrix", "ldpc_encode", "encode_message", "frame_bits", "modulate_frame",
-    "random_message", "Ping", "synth_audio", "synth_iq", "stream_s1", "stream_s2", "stream_s3", "pack_bits_msb",
+    "random_message", "Ping", "synth_audio", "synth_iq", "stream_s1", "stream_s2", "stream_s3", "pack_bits_msb", "iq_low_snr_batch",
 ]
 
 _PP = np.sin(np.arange(12) * np.pi / 12.0)
@@ -240,3 +240,21 @@ def windows_of(stream: np.ndarray, read_mode: int = 1):
         out.append(stream[s:s + win])
         s += hop
     return out
+
+
+def iq_low_snr_batch(n_channels: int, seed: int = 5):
+    """BASELINE configs[4] workload: one int8 I/Q window per channel (S3 style): complex AWGN sigma = 20 LSB per
+    rail; every 4th channel carries one ping of 3-6 frames at -6..-2 dB, carrier within +-240 Hz of 0 Hz.
+    Returns (windows int8 [n][2*5184], {channel: packed 10-byte payload})."""
+    rng = np.random.default_rng(seed)
+    wins = np.empty((n_channels, 2 * WINDOW_SAMPLES), dtype=np.int8)
+    truth = {}
+    for ch in range(n_channels):
+        pings = []
+        if ch % 4 == 0:
+            msg = random_message(rng)
+            pings = [Ping(msg, int(rng.integers(0, 1500)), int(rng.integers(3, 7)), float(rng.uniform(-240, 240)), float(rng.uniform(-6, -2)),
+                          float(rng.uniform(0, 6.28)))]
+            truth[ch] = bytes(np.packbits(np.concatenate([msg, np.zeros(3, np.uint8)])))
+        wins[ch] = synth_iq(WINDOW_SAMPLES, pings, 20.0, rng)
+    return wins, truth

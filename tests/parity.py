@@ -9,7 +9,9 @@ sincos/tanh/sqrt implementations, FMA, wave64 reduction trees), so the contract 
   * LLR                          |diff| <= 1e-3 * max(1, |llr|)
   * integers (pos, nbadsync, index list, accept/iter/nhard, 77 bits) exact, except where the deciding
     real value lies within tolerance of its threshold; every such exception is verified to BE a
-    near-tie against the oracle and counted, never waved through.
+    near-tie against the oracle and counted, never waved through: scan arg-max swaps against the oracle's
+    own xb values, nbadsync against the oracle's sync softbits, BP accept/iteration differences by showing
+    that the oracle's own decision flips under LLR perturbations of 1e-6 .. 1e-4 (verify_marginal_bp).
 
 Masks 111111 and 100100 make the folded correlation exactly periodic in the position (864 and 2592
 samples: the same frames are summed), so their arg-max has mathematically exact ties that only
@@ -116,10 +118,38 @@ def compare_softbits(o, cd, items_o, items_g):
     return dict(llr_max_abs_diff=float(np.abs(exp_llr[finite] - got[finite]).max()) if finite.any() else 0.0, nbadsync_marginal=marginal)
 
 
+BP_PERTURBATION_SCALES = (1e-6, 1e-5, 1e-4)   # relative LLR perturbations, all far inside the stated LLR tolerance (1e-3)
+
+
+def bp_outcome(orc_mod, llr):
+    ok, msg, it, nh = orc_mod.ldpc_one(np.ascontiguousarray(llr, dtype=np.float32))
+    return (bool(ok), int(it) if ok else -1, int(nh) if ok else -1, bytes(np.asarray(msg, dtype=np.uint8)) if ok else b"")
+
+
+def verify_marginal_bp(orc_mod, llr, gpu_outcome, seed, trials=48):
+    """A BP accept/iteration difference between the HIP kernel and the oracle is tolerated ONLY if the oracle's own decision
+    is unstable at that input: re-running the oracle's BP on the same LLRs perturbed by a relative 1e-6 .. 1e-4 (the kernel's
+    tanh/atanh differ from libm by ~1e-7) must reproduce the kernel's (accept, iteration) outcome in some trial AND the
+    oracle's in another.  Returns the smallest scale at which that happens; raises AssertionError for a stable difference."""
+    llr = np.ascontiguousarray(llr, dtype=np.float32)
+    rng = np.random.default_rng(seed)
+    base = bp_outcome(orc_mod, llr)[:2]
+    for scale in BP_PERTURBATION_SCALES:
+        seen = {base}
+        for _ in range(trials):
+            pert = (llr * (1.0 + scale * rng.uniform(-1.0, 1.0, size=llr.shape))).astype(np.float32)
+            seen.add(bp_outcome(orc_mod, pert)[:2])
+            if tuple(gpu_outcome[:2]) in seen and len(seen) > 1:
+                return scale
+    raise AssertionError(("BP decision differs from the oracle and is STABLE under LLR perturbations up to 1e-4: not a marginal case",
+                          dict(oracle=base, gpu=tuple(gpu_outcome[:2]))))
+
+
 def compare_ldpc_against_oracle_on_gpu_llrs(orc_mod, items_g, threshold):
-    """Run the oracle's BP on the LLRs the GPU produced; accept/iter/nhard/message must be identical
-    (tanh ulp differences can flip a marginal case: counted and bounded)."""
-    flips = 0
+    """Run the oracle's BP on the LLRs the GPU produced; accept/iter/nhard/message must be identical.  A difference is
+    accepted only after verify_marginal_bp has shown the decision to be unstable at that input; such cases are counted
+    with the perturbation scale that exposed them."""
+    flips = []
     checked = 0
     for k in range(len(items_g)):
         if items_g["nbadsync"][k] > threshold:
@@ -128,17 +158,46 @@ def compare_ldpc_against_oracle_on_gpu_llrs(orc_mod, items_g, threshold):
         llr = items_g["softbits_wo_sync"][k]
         if not np.isfinite(llr).all():
             continue
-        ok, msg, it, nh = orc_mod.ldpc_one(llr)
+        ok, it, nh, msg = bp_outcome(orc_mod, llr)
         checked += 1
-        if bool(items_g["is_message_present"][k]) != ok:
-            flips += 1
+        g_ok = bool(items_g["is_message_present"][k])
+        g_it = int(items_g["ldpc_num_iterations"][k]) if g_ok else -1
+        if g_ok == ok and g_it == it:
+            if ok:
+                assert msg == bytes(np.asarray(items_g["message"][k], dtype=np.uint8)), k
+                assert nh == items_g["ldpc_num_hard_errors"][k], k
             continue
-        if ok:
-            assert np.array_equal(msg, items_g["message"][k]), k
-            assert nh == items_g["ldpc_num_hard_errors"][k], k
-            if it != items_g["ldpc_num_iterations"][k]:
-                flips += 1
-    return dict(checked=checked, marginal_flips=flips)
+        scale = verify_marginal_bp(orc_mod, llr, (g_ok, g_it), seed=1000 + k)
+        flips.append(dict(item=int(k), oracle=[ok, it], gpu=[g_ok, g_it], unstable_at_relative_perturbation=scale))
+    return dict(checked=checked, marginal_flips=len(flips), flips=flips)
+
+
+def compare_ldpc_items(orc_mod, items_o, items_g, same):
+    """Full-window form: items_o are the oracle's results on the oracle's own LLRs; for every candidate in `same` (identical
+    position and nbadsync) accept/iteration/hard errors/payload must be identical, except verified-marginal cases (the LLRs
+    themselves differ by <= 1e-3 there, so the perturbation test is run around the GPU's LLRs with the oracle's outcome as the
+    second required outcome)."""
+    flips = []
+    idx = np.nonzero(same & ((items_o["is_message_present"] != items_g["is_message_present"]) |
+                             ((items_o["is_message_present"] == 1) & (items_o["ldpc_num_iterations"] != items_g["ldpc_num_iterations"]))))[0]
+    for k in idx:
+        g_ok = bool(items_g["is_message_present"][k])
+        g_it = int(items_g["ldpc_num_iterations"][k]) if g_ok else -1
+        o_ok = bool(items_o["is_message_present"][k])
+        o_it = int(items_o["ldpc_num_iterations"][k]) if o_ok else -1
+        llr = items_g["softbits_wo_sync"][k]
+        on_gpu_llr = bp_outcome(orc_mod, llr)[:2]
+        if on_gpu_llr == (g_ok, g_it):
+            # the kernel agrees with the oracle's BP on its own LLRs; the difference comes from the (toleranced) LLRs:
+            # it must then be reachable from the oracle's LLRs by a perturbation inside the LLR tolerance
+            scale = verify_marginal_bp(orc_mod, items_o["softbits_wo_sync"][k], (g_ok, g_it), seed=2000 + int(k))
+        else:
+            scale = verify_marginal_bp(orc_mod, llr, (g_ok, g_it), seed=2000 + int(k))
+        flips.append(dict(item=int(k), oracle=[o_ok, o_it], gpu=[g_ok, g_it], unstable_at_relative_perturbation=scale))
+    both = same & (items_o["is_message_present"] == 1) & (items_g["is_message_present"] == 1)
+    assert np.array_equal(items_o["message"][both], items_g["message"][both])
+    assert np.array_equal(items_o["ldpc_num_hard_errors"][both], items_g["ldpc_num_hard_errors"][both])
+    return dict(compared=int(same.sum()), both_accepted=int(both.sum()), marginal_flips=len(flips), flips=flips)
 
 
 def decoded_set(items):

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 DEEP = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
 
 
-def test_deep_window_against_oracle(orc, hip):
+def test_deep_window_against_oracle(orc, hip, parity_report):
     """One full-size window, every stage compared with the oracle (about 1 s of 16 host cores)."""
     rng = np.random.default_rng(2025)
     msg = synth.random_message(rng)
@@ -31,14 +31,12 @@ def test_deep_window_against_oracle(orc, hip):
     assert sb["nbadsync_marginal"] <= 8, sb
     assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= 3)[0])
     same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
-    # accept / iterations / hard errors / payload identical wherever the candidate itself is identical
-    flips = int((items_o["is_message_present"][same] != items_g["is_message_present"][same]).sum())
-    assert flips <= 2, flips
-    both = same & (items_o["is_message_present"] == 1) & (items_g["is_message_present"] == 1)
-    assert both.sum() > 10
-    assert np.array_equal(items_o["message"][both], items_g["message"][both])
-    assert np.array_equal(items_o["ldpc_num_hard_errors"][both], items_g["ldpc_num_hard_errors"][both])
-    assert (items_o["ldpc_num_iterations"][both] != items_g["ldpc_num_iterations"][both]).sum() <= 2
+    # accept / iterations / hard errors / payload identical wherever the candidate itself is identical; any difference
+    # must be a VERIFIED marginal case (oracle decision unstable under 1e-6..1e-4 LLR perturbations)
+    ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
+    assert ld["marginal_flips"] <= 4, ld
+    assert ld["both_accepted"] > 10
+    parity_report("deep_window_F501_D6", dict(scan=rep, softbits=sb, ldpc=ld))
     assert bytes(msg) in parity.decoded_messages(items_g)
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
 
@@ -80,7 +78,7 @@ def test_1024_channel_batch_properties(orc, hip):
             assert d1.dump_candidates(0).tobytes() == blob              # batch == single, bit for bit
 
 
-def test_fine_step_depth8_all_gated(orc, hip):
+def test_fine_step_depth8_all_gated(orc, hip, parity_report):
     """Quarter-Hz grid, all 8 patterns, threshold 16 (every candidate is BP-decoded): F=401, 25 664 candidates."""
     cfg = dict(center=1500.0, width=100.0, step=0.25, depth=8, nbadsync_threshold=16)
     rng = np.random.default_rng(77)
@@ -100,7 +98,59 @@ def test_fine_step_depth8_all_gated(orc, hip):
     rep = parity.compare_scan(o, cd, items_o, items_g)
     assert rep["near_ties"] <= 26, rep
     parity.compare_softbits(o, cd, items_o, items_g)
-    same = items_o["pos"] == items_g["pos"]
-    assert (items_o["is_message_present"][same] != items_g["is_message_present"][same]).sum() <= 2
+    same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
+    ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
+    assert ld["marginal_flips"] <= 4, ld
+    parity_report("fine_step_depth8_all_gated", dict(scan=rep, ldpc=ld))
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
     assert bytes(msg) in parity.decoded_messages(items_g)
+
+
+def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
+    """BASELINE configs[4] at full size: IQ --read-mode=2, 4096 low-SNR channels, width 500 / step 1 (BASELINE leaves the step
+    open; 1 Hz = the deep setting, F=501) / depth 6 / nbadsync-threshold 3 - the LDPC-iteration-heavy stress (main.cu:334-380).
+    Determinism, batch == single channel bit for bit, every payload that was not transmitted reproduced by the oracle at the same
+    item, and most pinged channels decoded."""
+    cfg = dict(center=0.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
+    nch = 4096
+    wins, truth = synth.iq_low_snr_batch(nch, 5)
+    with hip.HipDecoder(read_mode=2, channels=nch, max_results=1 << 20, **cfg) as d:
+        assert (d.F, d.D, d.K) == (501, 6, 24048)
+        d.submit_iq(wins)
+        d.decode()
+        res1 = d.results().copy()
+        blobs = {ch: d.dump_candidates(ch).tobytes() for ch in (0, 1, 2047, 4095)}
+        d.submit_iq(wins)
+        d.decode()
+        res2 = d.results().copy()
+    assert res1.tobytes() == res2.tobytes()                             # deterministic
+    key = res1["channel"].astype(np.int64) * 100000 + res1["item"]
+    assert np.all(np.diff(key) > 0)                                     # ordered by (channel, item)
+    good = {int(r["channel"]) for r in res1 if truth.get(int(r["channel"])) == bytes(r["message"])}
+    assert len(good) >= 0.75 * len(truth), (len(good), len(truth))      # -6..-2 dB pings: most decode
+    unexpected = [r for r in res1 if truth.get(int(r["channel"])) != bytes(r["message"])]
+    assert len(unexpected) <= 16, len(unexpected)                       # CRC-13 false positives of the algorithm itself
+    o = orc.Oracle(threads=16, **cfg)
+    for r in unexpected[:8]:
+        ch, k = int(r["channel"]), int(r["item"])
+        items, _ = o.decode_window(o.frontend_iq(wins[ch]))
+        assert items["is_message_present"][k] == 1
+        assert bytes(np.packbits(np.concatenate([items["message"][k].astype(np.uint8), np.zeros(3, np.uint8)]))) == bytes(r["message"])
+    with hip.HipDecoder(read_mode=2, channels=1, **cfg) as d1:
+        for ch, blob in blobs.items():
+            d1.submit_iq(wins[ch])
+            d1.decode()
+            assert d1.dump_candidates(0).tobytes() == blob              # batch == single, bit for bit
+            if ch == 0:
+                # one pinged channel end to end against the oracle, stage by stage
+                cd = o.frontend_iq(wins[ch])
+                assert np.array_equal(d1.dump_analytic(0).view(np.uint32), cd.view(np.uint32))
+                items_o, _ = o.decode_window(cd)
+                items_g = d1.dump_candidates(0)
+                rep = parity.compare_scan(o, cd, items_o, items_g)
+                sb = parity.compare_softbits(o, cd, items_o, items_g)
+                same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
+                ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
+                assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
+    parity_report("config4_iq_4096", dict(channels=nch, decodes=int(len(res1)), pinged=len(truth), pinged_decoded=len(good),
+                                          not_transmitted=len(unexpected), channel0=dict(scan=rep, softbits=sb, ldpc=ld)))

@@ -22,16 +22,7 @@ with HipDecoder(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshol
 
 # --- configs[4]: IQ, 4096 low-SNR channels, depth 6, threshold 3, width 500 step 1 ---
 nch = int(os.environ.get("IQ_CH", "4096"))
-rng = np.random.default_rng(5)
-wins = np.empty((nch, 2 * 5184), dtype=np.int8)
-truth = {}
-for ch in range(nch):
-    pings = []
-    if ch % 4 == 0:
-        msg = synth.random_message(rng)
-        pings = [synth.Ping(msg, int(rng.integers(0, 1500)), int(rng.integers(3, 7)), float(rng.uniform(-240, 240)), float(rng.uniform(-6, -2)), float(rng.uniform(0, 6.28)))]
-        truth[ch] = bytes(np.packbits(np.concatenate([msg, np.zeros(3, np.uint8)])))
-    wins[ch] = synth.synth_iq(5184, pings, 20.0, rng)
+wins, truth = synth.iq_low_snr_batch(nch, 5)
 dev = torch.from_numpy(wins).cuda()
 with HipDecoder(center=0.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3, read_mode=2, channels=nch, max_results=1 << 20) as d:
     d.set_stream(torch.cuda.current_stream().cuda_stream)
