@@ -151,11 +151,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     float2 xin[kOutPerThread];  // all nine loads in flight before any arithmetic: one L2 latency per tile, not three
 #pragma unroll
     for(int i = 0; i < kOutPerThread; i++) xin[i] = cdat[tid + i * kScanThreads];
+    const float tid_f = static_cast<float>(tid);
 #pragma unroll
     for(int i = 0; i < kOutPerThread; i++)
     {
         const int n = tid + i * kScanThreads;
-        const float2 y = mix_sample(xin[i], n, f0);
+        const float2 y = mix_sample(xin[i], tid_f + static_cast<float>(i * kScanThreads), f0);
         s_buf[n] = y;
         if(n < kWrapPad) s_buf[kWindowSamples + n] = y;
     }

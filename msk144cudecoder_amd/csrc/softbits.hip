@@ -93,13 +93,14 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
             const int n = tid + i * kSbThreads;
             xin[i] = n < kWindowSamples ? cdat[n] : make_float2(0.0f, 0.0f);
         }
+        const float tid_f = static_cast<float>(tid);
 #pragma unroll
         for(int i = 0; i < kPerThread; i++)
         {
             const int n = tid + i * kSbThreads;
             if(n < kWindowSamples)
             {
-                const float2 y = mix_sample(xin[i], n, f0);
+                const float2 y = mix_sample(xin[i], tid_f + static_cast<float>(i * kSbThreads), f0);
                 s_x[n] = y;
                 if(n < kRunPad) s_x[kWindowSamples + n] = y;
             }
