@@ -97,7 +97,7 @@ class HipBackend:
     dist_backend = "nccl"
     data = "synthetic"
 
-    def __init__(self, rank: int, local_rank: int, channels: int, channel_base: int, mode: str = "staged"):
+    def __init__(self, rank: int, local_rank: int, channels: int, channel_base: int, llr_block: int = 0):
         import torch
         from msk144cudecoder_amd.hipdecoder import RESULT_DTYPE, T_NAMES, HipDecoder  # fails loudly without the HIP library
         self.torch = torch
@@ -107,7 +107,8 @@ class HipBackend:
         self.wins_host, self.truth = make_inputs(rank, channels)
         self.wins_dev = torch.from_numpy(self.wins_host).cuda(local_rank)   # inputs resident in HBM before timing
         self.dec = HipDecoder(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, read_mode=1,
-                              analytic_method=2, channels=channels, device=local_rank, max_results=1 << 20)
+                              analytic_method=2, channels=channels, device=local_rank, max_results=1 << 20, llr_block_channels=llr_block)
+        self.llr_block = self.dec.params.llr_block_channels or min(channels, 64)
         self.dec.set_stream(torch.cuda.current_stream().cuda_stream)
         self.dec.set_channel_base(channel_base)
         self.channel_base = channel_base
@@ -164,6 +165,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=CHANNELS_PER_GPU, help="channels per GPU (default: the BASELINE config)")
+    ap.add_argument("--llr-block", type=int, default=0, help="channels per softbits->index->LDPC block (0 = library default; = channels: retain every LLR row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launcher", action="store_true", help="go through the N-rank launcher even for --gpus 1 (exercises the RCCL gather path)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
@@ -231,7 +233,7 @@ def run_worker(args) -> int:
 
     channels = args.channels
     channel_base, _ = sharding.shard_channels(channels * world, rank, world)   # rank r owns global channels [r*C, (r+1)*C)
-    be = Backend(rank, local_rank, channels, channel_base)
+    be = Backend(rank, local_rank, channels, channel_base, args.llr_block)
     cand_per_step = be.cand_per_step
 
     gather = None
@@ -328,7 +330,7 @@ def run_worker(args) -> int:
             "config": {"workload": f"BASELINE configs[2]: {channels} synthetic 12 ksps int16 audio channels per GPU, one 5184-sample window per "
                                    f"channel per step, width=500 step=1 depth=6 nbadsync-threshold=3 (F={be.F}, D={be.D}, {be.K} candidates/window)",
                        "channels_per_gpu": channels, "candidates_per_step_per_gpu": cand_per_step, "parallelism": f"channel-shard x{world}",
-                       "analytic_method": 2, "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
+                       "analytic_method": 2, "llr_block_channels": getattr(be, "llr_block", None), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
                        "real_time_channels": value / be.K / (12000.0 / 2592.0)},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,

@@ -45,7 +45,9 @@ enum
     MSK144_EHIP = -2,     /* HIP runtime error (text in msk144_last_error) */
     MSK144_ENOMEM = -3,   /* device or host allocation failed */
     MSK144_ESTATE = -4,   /* call out of order (e.g. decode before submit) */
-    MSK144_EOVERFLOW = -5 /* more decodes than max_results; results truncated */
+    MSK144_EOVERFLOW = -5, /* more decodes than max_results; results truncated */
+    MSK144_ENOTRETAINED = -6 /* blocked staging does not retain what was asked for (LLR rows of an earlier block, or a partial
+                                stage run); create the handle with llr_block_channels = channels */
 };
 
 /* msk144_decode_stages bits, in launch order (main.cu:463-467) */
@@ -83,6 +85,13 @@ typedef struct msk144_params
     int32_t channels;       /* independent streams decoded per call (reference: 1) */
     int32_t device;         /* HIP device ordinal */
     int32_t max_results;    /* capacity of the compact result list; 0 = default */
+    int32_t llr_block_channels; /* channels per softbits->index->LDPC block (reference: result_keeper.cuh:105-115 keeps every
+                                   candidate's 128 softbits; ldpc_kernel.cuh:116-142 reads them back).  The LLR rows of a block
+                                   (block x items x 512 B) are produced and consumed back to back, so the LLR store never grows
+                                   with the batch (0.79 GB per 64-channel block at the deep config instead of 12.6 GB per 1024
+                                   channels).  0 = automatic: min(channels, 64) - measured +0.6 % step time at 64, +4 % at 16
+                                   (the per-block index launch).  Candidate dumps need every row retained:
+                                   = channels: retain everything (parity-dump mode) */
 } msk144_params;
 
 /* One accepted decode (CRC ok, < 18 hard errors), fields as the reference's host loop consumes them
@@ -173,8 +182,8 @@ int msk144_dump_indexes(msk144_handle* h, int32_t channel, int32_t* out /*[items
  * known inputs */
 int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candidate* items);
 
-/* per-stage device time (HIP events recorded on the decode stream around every launch), averaged
- * over the launches since the last reset; samples[s] = launches of stage s that were measured */
+/* per-stage device time (HIP events recorded on the decode stream around every launch), summed over the launches of one
+ * msk144_decode / msk144_submit_* call and averaged over the calls since the last reset; samples[s] = calls measured */
 int msk144_set_profiling(msk144_handle* h, int32_t enable);
 int msk144_stage_times(msk144_handle* h, float* avg_ms /*[MSK144_T_COUNT]*/, int32_t* samples /*[MSK144_T_COUNT] or NULL*/, int32_t reset);
 

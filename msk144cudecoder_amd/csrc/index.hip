@@ -45,7 +45,7 @@ __device__ __forceinline__ int ordered_slot(bool flag, int& base, int* s_wave_co
 __global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st)
 {
     __shared__ int s_wave_count[kIdxWaves];
-    const int ch = blockIdx.x;
+    const int ch = st.ch0 + blockIdx.x;
     const size_t off = static_cast<size_t>(ch) * st.K;
     const int32_t* __restrict__ nbad = st.nbadsync + off;
     int32_t* __restrict__ out = st.idx + off;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kIdxThreads) void collect_scatter_kernel(const Devi
 
 void launch_index(const DeviceStore& st, hipStream_t stream)
 {
-    hipLaunchKernelGGL(index_kernel, dim3(st.channels), dim3(kIdxThreads), 0, stream, st);
+    hipLaunchKernelGGL(index_kernel, dim3(st.nch), dim3(kIdxThreads), 0, stream, st);
 }
 
 void launch_collect(const DeviceStore& st, hipStream_t stream)

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 {
     __shared__ float s_t[kLdpcWaves][kMaxCheckDegree * kTStride];
 
-    const int ch = blockIdx.y;
+    const int ch = st.ch0 + blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n_idx = st.n_idx[ch];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     for(int i = blockIdx.x * kLdpcWaves + wave; i < n_idx; i += gridDim.x * kLdpcWaves)
     {
         const int item = idx[i];
-        const float* __restrict__ L = st.llr + (off + item) * kCodeBits;
+        const float* __restrict__ L = st.llr + (static_cast<size_t>(blockIdx.y) * st.K + item) * kCodeBits;
         const float llr[2] = {L[lane], L[lane + 64]};
         const float llr_s[2] = {llr[0] * kLog2e, llr[1] * kLog2e};  // log2-scaled copy used by the message passing
         float tov[2][kEdgesPerBit] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
@@ -285,10 +285,10 @@ void launch_ldpc(const DeviceStore& st, hipStream_t stream)
 {
     // enough waves to fill 256 CUs x 8 waves/SIMD x 4 SIMDs even for one channel
     const int max_waves_per_channel = (st.K + kLdpcWaves - 1) / kLdpcWaves;
-    int blocks = (8192 + st.channels - 1) / st.channels;
+    int blocks = (8192 + st.nch - 1) / st.nch;
     if(blocks > max_waves_per_channel) blocks = max_waves_per_channel;
     if(blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(ldpc_kernel, dim3(blocks, st.channels), dim3(kLdpcThreads), 0, stream, st);
+    hipLaunchKernelGGL(ldpc_kernel, dim3(blocks, st.nch), dim3(kLdpcThreads), 0, stream, st);
 }
 
 }  // namespace msk144

@@ -37,6 +37,7 @@ struct msk144_handle
     float* d_fft_mask = nullptr;
     std::vector<void*> allocs;
 
+    int llr_block = 1;  // channels per softbits->index->LDPC block
     bool have_window = false;
     bool decoded = false;
     bool profiling = false;
@@ -45,8 +46,11 @@ struct msk144_handle
     struct Span
     {
         int stage;
+        int call;  // spans of one decode/submit call are summed into one sample
         hipEvent_t e0, e1;
     };
+    int call_id = 0;
+    int last_call[MSK144_T_COUNT];
     std::vector<Span> spans_pending;
     std::vector<hipEvent_t> ev_free;
     hipEvent_t ev_open = nullptr;
@@ -129,7 +133,7 @@ void ev_end(msk144_handle* h, int stage)
         return;
     }
     (void)hipEventRecord(e1, h->stream);
-    h->spans_pending.push_back({stage, h->ev_open, e1});
+    h->spans_pending.push_back({stage, h->call_id, h->ev_open, e1});
     h->ev_open = nullptr;
 }
 
@@ -142,7 +146,11 @@ void harvest_times(msk144_handle* h)
         if(hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess)
         {
             h->t_sum[sp.stage] += ms;
-            h->t_cnt[sp.stage]++;
+            if(h->last_call[sp.stage] != sp.call)
+            {
+                h->last_call[sp.stage] = sp.call;
+                h->t_cnt[sp.stage]++;
+            }
         }
         h->ev_free.push_back(sp.e0);
         h->ev_free.push_back(sp.e1);
@@ -152,6 +160,7 @@ void harvest_times(msk144_handle* h)
 
 int run_frontend(msk144_handle* h, const void* d_in)
 {
+    h->call_id++;
     ev_begin(h, MSK144_T_FRONTEND);
     if(h->params.read_mode == 2) launch_frontend_iq(h->st, static_cast<const int8_t*>(d_in), h->stream);
     else launch_frontend_audio(h->st, static_cast<const int16_t*>(d_in), h->params.analytic_method, h->d_twiddle, h->d_fft_mask, h->stream);
@@ -180,6 +189,7 @@ void msk144_default_params(msk144_params* p)
     p->channels = 1;
     p->device = 0;
     p->max_results = 0;
+    p->llr_block_channels = 0;
 }
 
 const char* msk144_last_error(const msk144_handle* h)
@@ -194,6 +204,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     if(!(params->step_hz > 0.0f)) return fail(nullptr, MSK144_EINVAL, "search step must be > 0");  // assert at msk_context.cuh:97
     if(!(params->width_hz >= 0.0f)) return fail(nullptr, MSK144_EINVAL, "search width must be >= 0");
     if(params->channels < 1) return fail(nullptr, MSK144_EINVAL, "channels must be >= 1");
+    if(params->llr_block_channels < 0) return fail(nullptr, MSK144_EINVAL, "llr_block_channels must be >= 0");
     if(params->read_mode != 1 && params->read_mode != 2) return fail(nullptr, MSK144_EINVAL, "read_mode must be 1 (audio) or 2 (IQ)");
     if(params->read_mode == 1 && params->analytic_method != 1 && params->analytic_method != 2)
         return fail(nullptr, MSK144_EINVAL, "analytic_method must be 1 (FFT) or 2 (shift-filter-shift)");
@@ -202,6 +213,10 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     if(!h) return fail(nullptr, MSK144_ENOMEM, "out of host memory");
     h->params = *params;
     h->params.scan_depth = clamp_scan_depth(params->scan_depth);
+    h->llr_block = params->llr_block_channels > 0 ? params->llr_block_channels : (params->channels <= 64 ? params->channels : 64);
+    if(h->llr_block > params->channels) h->llr_block = params->channels;
+    h->params.llr_block_channels = h->llr_block;
+    for(int s = 0; s < MSK144_T_COUNT; s++) h->last_call[s] = -1;
 
     auto bail = [&](int code) {
         g_create_error = h->error;
@@ -235,6 +250,8 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     st.D = h->params.scan_depth;
     st.K = F * st.D * kSlotsPerPattern;
     st.nbadsync_threshold = params->nbadsync_threshold;
+    st.ch0 = 0;
+    st.nch = st.channels;
     const long long total = static_cast<long long>(st.channels) * st.K;
     long long maxr = params->max_results > 0 ? params->max_results : (1 << 20);
     if(maxr > total) maxr = total;
@@ -260,7 +277,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     A(dev_alloc(h, &st.pos, ck));
     A(dev_alloc(h, &st.xb, ck));
     A(dev_alloc(h, &st.nbadsync, ck));
-    A(dev_alloc(h, &st.llr, ck * kCodeBits));
+    A(dev_alloc(h, &st.llr, static_cast<size_t>(h->llr_block) * st.K * kCodeBits));
     A(dev_alloc(h, &st.idx, ck));
     A(dev_alloc(h, &st.n_idx, st.channels));
     A(dev_alloc(h, &st.dec_flag, ck));
@@ -408,30 +425,45 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
 {
     if(!h) return MSK144_EINVAL;
     if((stages & (MSK144_STAGE_SCAN | MSK144_STAGE_SOFTBITS)) && !h->have_window) return fail(h, MSK144_ESTATE, "decode before any window was submitted");
+    const bool blocked = h->llr_block < h->st.channels;
+    const uint32_t mid = MSK144_STAGE_SOFTBITS | MSK144_STAGE_INDEX | MSK144_STAGE_LDPC;
+    if(blocked && (stages & mid) != 0 && (stages & mid) != mid)
+        return fail(h, MSK144_ENOTRETAINED, "blocked staging runs softbits, index and LDPC together per channel block; a partial stage run needs llr_block_channels = channels");
     HIP_TRY(h, hipSetDevice(h->params.device));
+    h->call_id++;
     if(stages & MSK144_STAGE_SCAN)
     {
         ev_begin(h, MSK144_T_SCAN);
         launch_scan(h->st, h->tpl, h->stream);
         ev_end(h, MSK144_T_SCAN);
     }
-    if(stages & MSK144_STAGE_SOFTBITS)
+    // softbits -> index -> LDPC, one channel block at a time (one block = everything unless llr_block_channels says otherwise)
+    if(stages & mid)
     {
-        ev_begin(h, MSK144_T_SOFTBITS);
-        launch_softbits(h->st, h->tpl, h->stream);
-        ev_end(h, MSK144_T_SOFTBITS);
-    }
-    if(stages & MSK144_STAGE_INDEX)
-    {
-        ev_begin(h, MSK144_T_INDEX);
-        launch_index(h->st, h->stream);
-        ev_end(h, MSK144_T_INDEX);
-    }
-    if(stages & MSK144_STAGE_LDPC)
-    {
-        ev_begin(h, MSK144_T_LDPC);
-        launch_ldpc(h->st, h->stream);
-        ev_end(h, MSK144_T_LDPC);
+        DeviceStore blk = h->st;
+        for(int ch0 = 0; ch0 < h->st.channels; ch0 += h->llr_block)
+        {
+            blk.ch0 = ch0;
+            blk.nch = h->st.channels - ch0 < h->llr_block ? h->st.channels - ch0 : h->llr_block;
+            if(stages & MSK144_STAGE_SOFTBITS)
+            {
+                ev_begin(h, MSK144_T_SOFTBITS);
+                launch_softbits(blk, h->tpl, h->stream);
+                ev_end(h, MSK144_T_SOFTBITS);
+            }
+            if(stages & MSK144_STAGE_INDEX)
+            {
+                ev_begin(h, MSK144_T_INDEX);
+                launch_index(blk, h->stream);
+                ev_end(h, MSK144_T_INDEX);
+            }
+            if(stages & MSK144_STAGE_LDPC)
+            {
+                ev_begin(h, MSK144_T_LDPC);
+                launch_ldpc(blk, h->stream);
+                ev_end(h, MSK144_T_LDPC);
+            }
+        }
     }
     if(stages & MSK144_STAGE_COLLECT)
     {
@@ -519,6 +551,7 @@ int msk144_dump_analytic(msk144_handle* h, int32_t channel, float* out)
 int msk144_dump_candidates(msk144_handle* h, int32_t channel, msk144_candidate* out)
 {
     if(!h || !out || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
+    if(h->llr_block < h->st.channels) return fail(h, MSK144_ENOTRETAINED, "LLR rows are not retained in blocked staging; create the handle with llr_block_channels = channels for candidate dumps");
     int rc = msk144_synchronize(h);
     if(rc != MSK144_OK) return rc;
     const DeviceStore& st = h->st;
@@ -575,6 +608,7 @@ int msk144_dump_indexes(msk144_handle* h, int32_t channel, int32_t* out, int32_t
 int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candidate* items)
 {
     if(!h || !items || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
+    if(h->llr_block < h->st.channels) return fail(h, MSK144_ENOTRETAINED, "blocked staging cannot take loaded candidates; create the handle with llr_block_channels = channels");
     int rc = msk144_synchronize(h);
     if(rc != MSK144_OK) return rc;
     const DeviceStore& st = h->st;

@@ -30,6 +30,12 @@ struct DeviceStore
     int32_t nbadsync_threshold;
     int32_t max_results;
     int32_t channel_base;     // added to the channel number in result records (multi-GPU sharding)
+    // Blocked staging: softbits / index / LDPC are launched per block of channels [ch0, ch0 + nch), so the LLR store is
+    // llr_block x K x 512 B however large the batch is (a 64-channel block: 0.79 GB at the deep config; the reference keeps
+    // 512 B of softbits in every 632-byte item).  llr is indexed by (channel - ch0), every other array by the absolute
+    // channel.  scan, front ends and collect always cover all `channels`.
+    int32_t ch0;
+    int32_t nch;
 
     const float* freq;        // [F] Hz, host-computed as msk_context.cuh:135
     const float2* cb42;       // [42] sync template (re, im), for kernels that index it per lane
@@ -39,7 +45,7 @@ struct DeviceStore
     uint32_t* pos;            // [channels][K]
     float* xb;                // [channels][K]
     int32_t* nbadsync;        // [channels][K]
-    float* llr;               // [channels][K][128]
+    float* llr;               // [llr_block][K][128], row of (channel, item) = ((channel - ch0) * K + item) * 128
     int32_t* idx;             // [channels][K] gated item numbers, ascending
     int32_t* n_idx;           // [channels]
     uint8_t* dec_flag;        // [channels][K] is_message_present

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
     const int xcd = blockIdx.x & 7;
     const int tile = xcd * a.tiles_per_xcd + (blockIdx.x >> 3);
     if((blockIdx.x >> 3) >= a.tiles_per_xcd || tile >= a.total_tiles) return;
-    const int ch = tile / a.st.F;
-    const int b = tile - ch * a.st.F;
+    const int ch_rel = tile / a.st.F;  // channel inside the block [ch0, ch0 + nch)
+    const int b = tile - ch_rel * a.st.F;
+    const int ch = a.st.ch0 + ch_rel;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         const int nbad = __popcll(__ballot(disagree));
 
         // ---- store (softbits_kernel.cuh:204-211,244-247) ----
-        float* __restrict__ llr = a.st.llr + item * kCodeBits;
+        float* __restrict__ llr = a.st.llr + (item - static_cast<size_t>(a.st.ch0) * a.st.K) * kCodeBits;
         if(lane >= 8 && lane < 56) llr[lane - 8] = f32_mul(scale, soft[0]);      // u = 8..55    -> 0..47
         llr[48 + lane] = f32_mul(scale, soft[1]);                                // u = 64..127  -> 48..111
         if(lane < 16) llr[112 + lane] = f32_mul(scale, soft[2]);                 // u = 128..143 -> 112..127
@@ -295,7 +296,7 @@ void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t
     SoftbitsArgs a;
     a.st = st;
     a.tpl = tpl;
-    a.total_tiles = st.channels * st.F;
+    a.total_tiles = st.nch * st.F;
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
     const int grid = a.tiles_per_xcd * 8;
     hipLaunchKernelGGL(softbits_kernel, dim3(grid), dim3(kSbThreads), 0, stream, a);

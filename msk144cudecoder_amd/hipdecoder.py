@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
 class Params(C.Structure):
     _fields_ = [("center_hz", C.c_float), ("width_hz", C.c_float), ("step_hz", C.c_float), ("scan_depth", C.c_int32),
                 ("nbadsync_threshold", C.c_int32), ("read_mode", C.c_int32), ("analytic_method", C.c_int32), ("channels", C.c_int32),
-                ("device", C.c_int32), ("max_results", C.c_int32)]
+                ("device", C.c_int32), ("max_results", C.c_int32), ("llr_block_channels", C.c_int32)]
 
 
 RESULT_DTYPE = np.dtype([
@@ -119,9 +119,9 @@ class HipDecoder:
     """One msk144_handle: `channels` independent windows per decode on one MI355X."""
 
     def __init__(self, center=1500.0, width=200.0, step=2.0, depth=4, nbadsync_threshold=1, read_mode=1, analytic_method=2,
-                 channels=1, device=0, max_results=0):
+                 channels=1, device=0, max_results=0, llr_block_channels=0):
         self.L = load_library()
-        p = Params(center, width, step, depth, nbadsync_threshold, read_mode, analytic_method, channels, device, max_results)
+        p = Params(center, width, step, depth, nbadsync_threshold, read_mode, analytic_method, channels, device, max_results, llr_block_channels)
         self.params = p
         self.h = C.c_void_p()
         rc = self.L.msk144_create(C.byref(p), C.byref(self.h))

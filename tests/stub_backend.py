@@ -13,7 +13,7 @@ class Backend:
     dist_backend = "gloo"
     data = "stub (no decoding, test only)"
 
-    def __init__(self, rank, local_rank, channels, channel_base, mode="staged"):
+    def __init__(self, rank, local_rank, channels, channel_base, llr_block=0):
         self.T_NAMES = T_NAMES
         self.device = torch.device("cpu")
         self.F, self.D, self.K = 3, 2, 48

@@ -40,7 +40,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_struct_layouts(lib):
     _, hd = lib
-    assert C.sizeof(hd.Params) == 40
+    assert C.sizeof(hd.Params) == 44
     assert hd.RESULT_DTYPE.itemsize == 52
     assert hd.CANDIDATE_DTYPE.itemsize == 632
     offs = {n: hd.CANDIDATE_DTYPE.fields[n][1] for n in hd.CANDIDATE_DTYPE.names}

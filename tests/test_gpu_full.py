@@ -47,7 +47,7 @@ def test_1024_channel_batch_properties(orc, hip):
     algorithm itself are expected at 1.6e7 BP attempts per step and must be the oracle's too)."""
     import bench
     wins, truth = bench.make_inputs(0, 1024)
-    with hip.HipDecoder(channels=1024, max_results=1 << 20, **DEEP) as d:
+    with hip.HipDecoder(channels=1024, max_results=1 << 20, llr_block_channels=1024, **DEEP) as d:   # parity-dump mode: every LLR row retained
         d.submit_audio(wins[2])
         d.decode()
         res1 = d.results().copy()
@@ -114,7 +114,7 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
     cfg = dict(center=0.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
     nch = 4096
     wins, truth = synth.iq_low_snr_batch(nch, 5)
-    with hip.HipDecoder(read_mode=2, channels=nch, max_results=1 << 20, **cfg) as d:
+    with hip.HipDecoder(read_mode=2, channels=nch, max_results=1 << 20, llr_block_channels=nch, **cfg) as d:   # parity-dump mode (50 GB of LLRs)
         assert (d.F, d.D, d.K) == (501, 6, 24048)
         d.submit_iq(wins)
         d.decode()
@@ -154,3 +154,28 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
                 assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
     parity_report("config4_iq_4096", dict(channels=nch, decodes=int(len(res1)), pinged=len(truth), pinged_decoded=len(good),
                                           not_transmitted=len(unexpected), channel0=dict(scan=rep, softbits=sb, ldpc=ld)))
+
+
+def test_blocked_staging_equals_retained(hip):
+    """Blocked staging (LLR rows of 64 channels at a time, the production default for big batches) must give exactly the result
+    list of the retain-everything mode; candidate dumps and partial stage runs are refused rather than served stale."""
+    import bench
+    wins, _ = bench.make_inputs(0, 200)
+    with hip.HipDecoder(channels=200, max_results=1 << 20, llr_block_channels=200, **DEEP) as d:
+        d.submit_audio(wins[1])
+        d.decode()
+        want = d.results().copy()
+    for blk in (0, 16, 7, 64):          # 0 = automatic (64 for more than 64 channels); 7: last block is short
+        with hip.HipDecoder(channels=200, max_results=1 << 20, llr_block_channels=blk, **DEEP) as d:
+            d.submit_audio(wins[1])
+            d.decode()
+            got = d.results().copy()
+            assert got.tobytes() == want.tobytes(), blk
+            with pytest.raises(hip.Msk144Error) as e:
+                d.dump_candidates(3)
+            assert e.value.code == -6
+            with pytest.raises(hip.Msk144Error) as e:
+                d.decode(hip.STAGE_LDPC)
+            assert e.value.code == -6
+            d.decode(hip.STAGE_SCAN)        # stages outside the block loop stay individually runnable
+    assert len(want) > 100
