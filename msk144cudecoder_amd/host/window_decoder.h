@@ -26,11 +26,12 @@ struct DecoderOptions
     int analytic_method = 2;
     int device = 0;
     int channels = 1;  // independent input streams decoded together (the reference: 1)
-    // The reference keys its per-window decode cache with a comparator that is always false
-    // (main.cu:437-445), so every accepted candidate of a window receives the text - or the unpack
-    // failure - of the FIRST accepted candidate.  true (default) reproduces that; false unpacks every
-    // distinct payload (--strict-decode).
-    bool reference_cache_quirk = true;
+    // The reference keys its per-window decode cache with a comparator that is always false (main.cu:437-445), so every
+    // accepted candidate of a window receives the text - or the unpack failure - of the FIRST accepted candidate: one CRC-13
+    // false positive at a lower frequency bin silences every genuine decode of that window, and a second station is printed
+    // with the first one's text.  false (default): every distinct payload is unpacked on its own.  true
+    // (--reference-decode-cache): reproduce the reference, for byte-for-byte stdout parity on inputs where it matters.
+    bool reference_cache_quirk = false;
     bool print_bits = false;  // append the 77-bit payload to each line (debug)
 };
 

@@ -42,7 +42,7 @@ def windows_of(stream: np.ndarray, read_mode: int):
         s += hop
 
 
-def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, quirk: bool = True, threads: int = 8, mask_date: bool = True):
+def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, quirk: bool = False, threads: int = 8, mask_date: bool = True):
     """All output lines (without the final 'Done') the reference program would print for `stream`."""
     H = C.CDLL(HOST_SO)
     H.msk144host_table_new.restype = C.c_void_p
@@ -78,14 +78,15 @@ def main():
     ap.add_argument("--read-mode", type=int, default=1)
     ap.add_argument("--analytic-method", type=int, default=2)
     ap.add_argument("--nbadsync-threshold", type=int, default=1)
-    ap.add_argument("--strict-decode", action="store_true")
+    ap.add_argument("--reference-decode-cache", action="store_true")
+    ap.add_argument("--strict-decode", action="store_true", help="accepted for compatibility: per-payload decode is the default")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     a = ap.parse_args()
     center = a.center_frequency if a.center_frequency is not None else (1500.0 if a.read_mode == 1 else 0.0)
     raw = sys.stdin.buffer.read()
     stream = np.frombuffer(raw, dtype=np.int16 if a.read_mode == 1 else np.int8)
     cfg = dict(center=center, width=a.search_width, step=a.search_step, depth=a.scan_depth, nbadsync_threshold=a.nbadsync_threshold)
-    for line in decode_stream(stream, cfg, a.read_mode, a.analytic_method, quirk=not a.strict_decode, threads=a.threads, mask_date=False):
+    for line in decode_stream(stream, cfg, a.read_mode, a.analytic_method, quirk=a.reference_decode_cache, threads=a.threads, mask_date=False):
         print(line)
     print("Done")
 

@@ -148,6 +148,21 @@ def main():
     out["main_defaults"] = d
     cite["main_defaults"] = f"main.cu:{line_of(t, t.index('default_center_frequency_audio'))}-{line_of(t, t.index('int nbadsync_threshold'))}"
 
+    # ---- main.cu: help text (showHelp) and the labels of the stderr parameter block, as printed ----
+    body = t[t.index("void showHelp"):t.index("// clang-format on", t.index("void showHelp"))]
+    help_lines = []
+    for ln in body.splitlines():
+        m = re.search(r'std::cout << (.*) << std::endl;', ln)
+        if not m:
+            continue
+        parts = re.findall(r'"((?:[^"\\]|\\.)*)"|(prog)', m.group(1))
+        help_lines.append("".join("{prog}" if p[1] else p[0] for p in parts))
+    out["help_lines"] = help_lines
+    cite["help_lines"] = f"main.cu:{line_of(t, t.index('void showHelp')) + 3}-{line_of(t, t.index('void showHelp')) + 12}"
+    blk = t[t.index('std::cerr << "Actual parameters:"'):t.index("sm1.stop();")]
+    out["stderr_block_labels"] = re.findall(r'<< "([A-Z][^"]*?)(?:: |:)?"', blk)
+    cite["stderr_block_labels"] = f"main.cu:{line_of(t, t.index('Actual parameters:'))}-{line_of(t, t.index('sm1.stop();')) - 2}"
+
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")

@@ -1,0 +1,99 @@
+"""gfx950 data hazards around DPP instructions, checked on the compiled kernels (CPU only: hipcc cross-compiles).
+
+wave64.h carries hand-counted wait states inside inline-asm strings (hipcc inserts no hazard nops for asm statements):
+  * a DPP instruction needs >= 2 wait states after a VALU write of a VGPR it reads;
+  * a DPP instruction needs >= 5 wait states after a VALU write of EXEC (v_cmpx*).
+This test compiles every kernel source with the build's own flags, walks each straight-line stretch of the listing and
+asserts both rules for EVERY *_dpp instruction (the compiler's own included).  One wait state = one instruction issued in
+between; `s_nop N` counts N + 1.  A label or branch ends the look-back (hazards across control flow are the compiler's, and no
+asm statement of ours starts with fewer than 5 states of its own)."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from msk144cudecoder_amd import build as B
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def _listing(src, extra):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        cmd = [B._hipcc()] + [f for f in B.COMMON if f != "-fPIC"] + [f for f in extra if f not in ("-x", "hip")] + ["--cuda-device-only", "-S", os.path.join(B._CSRC, src), "-o", out]
+        subprocess.run(cmd, check=True, capture_output=True)
+        return open(out).read().splitlines()
+
+
+def check_listing(lines):
+    """Returns (number of DPP instructions checked, list of violations)."""
+    window = []      # straight-line history: (mnemonic, written vgprs, is_exec_write, wait_states_it_provides)
+    checked, bad = 0, []
+    for ln, raw in enumerate(lines, 1):
+        line = raw.split(";")[0].strip()
+        if not line or line.startswith((".", "//")):
+            continue
+        if line.endswith(":"):
+            window = []
+            continue
+        parts = line.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+            window = []
+            continue
+        if "_dpp" in op:
+            checked += 1
+            operands = [a.strip() for a in args.split(",")]
+            srcs = _regs(",".join(operands[1:]).split(" quad_perm")[0].split(" row_")[0].split(" wave_")[0])
+            states = 0
+            for mn, written, exec_write, provides in reversed(window):
+                if exec_write and states < 5:
+                    bad.append((ln, raw.strip(), f"only {states} wait states after {mn} (EXEC write), need 5"))
+                if written & srcs and states < 2:
+                    bad.append((ln, raw.strip(), f"only {states} wait states after {mn} writes v{sorted(written & srcs)}, need 2"))
+                states += provides
+                if states >= 5:
+                    break
+        written, exec_write, provides = set(), False, 1
+        if op == "s_nop":
+            provides = int(args.strip() or "0", 0) + 1
+        elif op.startswith("v_"):
+            if op.startswith("v_cmpx"):
+                exec_write = True
+            elif not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                first = args.split(",")[0]
+                written = _regs(first)
+        window.append((op, written, exec_write, provides))
+        if len(window) > 16:
+            window.pop(0)
+    return checked, bad
+
+
+def test_checker_catches_a_planted_hazard():
+    ok = ["\tv_add_f32_e32 v1, v2, v3", "\ts_nop 1", "\tv_max_f32_dpp v4, v1, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"]
+    assert check_listing(ok) == (1, [])
+    n, bad = check_listing(["\tv_add_f32_e32 v1, v2, v3", "\ts_nop 0", "\tv_max_f32_dpp v4, v1, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"])
+    assert n == 1 and len(bad) == 1 and "need 2" in bad[0][2]
+    n, bad = check_listing(["\tv_cmpx_gt_f32_e32 v1, v2", "\ts_nop 3", "\tv_max_f32_dpp v4, v5, v5 row_mirror row_mask:0xf bank_mask:0xf"])
+    assert len(bad) == 1 and "EXEC" in bad[0][2]
+    assert check_listing(["\tv_cmpx_gt_f32_e32 v1, v2", "\ts_nop 4", "\tv_max_f32_dpp v4, v5, v5 row_mirror row_mask:0xf bank_mask:0xf"])[1] == []
+
+
+@pytest.mark.parametrize("src,extra", [(s, e) for s, e in B.SOURCES if s.endswith(".hip")])
+def test_no_dpp_hazard_in_compiled_kernels(src, extra):
+    checked, bad = check_listing(_listing(src, extra))
+    assert not bad, bad[:5]
+    if src in ("scan.hip", "softbits.hip"):
+        assert checked > 20          # the kernels that carry the hand-written DPP reductions really were inspected

@@ -49,8 +49,11 @@ def test_cli_audio_stream(orc):
     # every line has the reference's field layout (main.cu:409-417)
     pat = re.compile(r"^\*\*\*  snr=[ -]?\d+; f0=\s*[\d.]+; num_avg=\d; nbadsync=\d+; pattern_idx=\d; date=X; msg='.*'; $")
     assert all(pat.match(l) for l in got)
-    # default mode reproduces the reference's first-candidate cache behaviour
-    rc, out2, _ = _run(args, stream.tobytes())
+    # the default is the per-payload decode; --strict-decode is still accepted and changes nothing
+    rc, out1, _ = _run(args, stream.tobytes())
+    assert [re.sub(r"date=\d{14}", "date=X", l) for l in out1.strip().split("\n")[:-1]] == want
+    # --reference-decode-cache reproduces the reference's first-candidate cache behaviour
+    rc, out2, _ = _run(args + ["--reference-decode-cache"], stream.tobytes())
     got2 = [re.sub(r"date=\d{14}", "date=X", l) for l in out2.strip().split("\n")[:-1]]
     assert got2 == _expected_lines(orc, stream, cfg, 1, quirk=True)
 
@@ -104,7 +107,7 @@ def test_cli_multi_stream_equals_single_streams(tmp_path):
         per_ch[int(m.group(1))].append("***  " + re.sub(r"date=\d{14}", "date=X", m.group(2)))
     for c in range(3):
         assert per_ch[c] == singles[c]
-    assert err.count("Incomplete read error") == 3 and "Input streams: 3" in err
+    assert err.count("Incomplete read error") == 3 and "3 input streams per GPU batch" in err
 
 
 def test_cli_s1_stream_light_config(orc):
@@ -119,3 +122,95 @@ def test_cli_s1_stream_light_config(orc):
     want = _expected_lines(orc, stream, cfg, 1, quirk=False)
     assert got == want
     assert "Left Boundary: 1450Hz" in err and "Right Boundary: 1550Hz" in err
+
+
+def test_stderr_parameter_block_is_the_references():
+    """main.cu:233-252: same labels, same order, values the reference would print for these options (F = 11, depth 3)."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_constants.json")))
+    rc, out, err = _run(["--search-width=20", "--search-step=2", "--scan-depth=3"], b"")
+    assert rc == 0 and out.strip() == "Done"
+    block = err.split("\n\n")[0].split("\n")
+    labels = [l for l in ref["stderr_block_labels"] if l != "Hz"]
+    assert len(block) == len(labels)
+    for line, label in zip(block, labels):
+        assert line.startswith(label.rstrip("(").rstrip(": ").rstrip(":")), (line, label)
+    assert block[:8] == ["Actual parameters:", "Center Frequency: 1500Hz", "Search Step: 2Hz", "Search Width: 20Hz", "Scan Depth: 3", "Left Boundary: 1490Hz",
+                         "Right Boundary: 1510Hz", "Read Mode: (Audio. 16 bits signed.)"]
+    assert block[8:] == ["Analytic Method: 2", "Badsync Threshold: 1", "Scan-kernel CUDA blocks: 11", "Scan-kernel CUDA threads: 256", "Softbit-kernel CUDA blocks: 11*24=264",
+                         "Softbit-kernel CUDA threads: 160"]
+
+
+def test_skip_wav_header_flag(orc):
+    """Off by default (the reference decodes a RIFF header as 22 samples, README.md:72); on: the first 44 bytes are dropped."""
+    rng = np.random.default_rng(91)
+    msg = synth.random_message(rng)
+    stream = synth.synth_audio(5184 + 2 * 2592, [synth.Ping(msg, 2000, 5, 1502.0, 5.0, 0.3)], 1000.0, rng)
+    args = ["--search-width=12", "--search-step=1", "--scan-depth=6"]
+    rc, plain, _ = _run(args, stream.tobytes())
+    rc, skipped, _ = _run(args + ["--skip-wav-header"], b"RIFF" + bytes(40) + stream.tobytes())
+    rc, not_skipped, _ = _run(args, b"RIFF" + bytes(40) + stream.tobytes())
+    strip = lambda o: [re.sub(r"date=\d{14}", "date=X", l) for l in o.strip().split("\n")]
+    assert strip(skipped) == strip(plain) and len(strip(plain)) >= 2
+    assert strip(not_skipped) != strip(plain)          # 22 extra samples shift the window alignment: different positions/lines
+
+
+def test_paced_fifos_one_stalled_stream_does_not_hold_the_batch(tmp_path):
+    """f-4: 64 FIFOs fed in real time (2592 samples per 216 ms, main.cu:284-294, 398-403).  Stream 5 stalls for three hops in the
+    middle: the other 63 keep their cadence (their hops are answered within the hop period), the stalled one is decoded when its
+    data arrives, and every stream's ping is found."""
+    import threading
+    import time
+    n_ch, n_hops = 64, 7
+    rng = np.random.default_rng(2718)
+    n = 5184 + n_hops * 2592
+    streams, msgs = [], []
+    calls = ["K1ABC", "W9XYZ", "G4ABC", "DL1XYZ", "JA1ABC", "VK2DEF", "OH8XYZ", "PA3GHI"]
+    for c in range(n_ch):
+        msg = pack77.pack_standard(calls[c % 8], calls[(c // 8) % 8 if (c // 8) % 8 != c % 8 else (c + 1) % 8], ("FN42", "EN37", "IO91", "JO62")[c % 4])   # always unpacks to text
+        msgs.append(msg)
+        streams.append(synth.synth_audio(n, [synth.Ping(msg, 6000 + 40 * c, 5, 1500.0 + (c % 9) - 4, 6.0, 0.1 * c)], 1000.0, rng).tobytes())
+    paths = []
+    for c in range(n_ch):
+        p = str(tmp_path / f"ch{c}.fifo")
+        os.mkfifo(p)
+        paths.append(p)
+    proc = subprocess.Popen([EXE, "--search-width=16", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2", "--print-bits", "--hop-timeout-ms=100",
+                             "--inputs=" + ",".join(paths)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    hop = 2592 * 2
+
+    def feed(c):
+        with open(paths[c], "wb", buffering=0) as f:
+            t0 = time.monotonic()
+            f.write(streams[c][:5184 * 2])
+            for h in range(n_hops):
+                due = t0 + 0.216 * (h + 1) + (0.75 if (c == 5 and h >= 2) else 0.0)      # stream 5: its hops 2.. arrive 0.75 s late
+                time.sleep(max(0.0, due - time.monotonic()))
+                f.write(streams[c][5184 * 2 + h * hop:5184 * 2 + (h + 1) * hop])
+
+    threads = [threading.Thread(target=feed, args=(c,)) for c in range(n_ch)]
+    t_start = time.monotonic()
+    for t in threads:
+        t.start()
+    out, err = proc.communicate(timeout=120)
+    wall = time.monotonic() - t_start
+    for t in threads:
+        t.join()
+    out, err = out.decode(), err.decode()
+    assert proc.returncode == 0, err[-2000:]
+    assert out.strip().split("\n")[-1] == "Done"
+    decoded = {}
+    for l in out.strip().split("\n")[:-1]:
+        m = re.match(r"^\*\*\*  ch=(\d+); .*bits='([01]{77})'; $", l)
+        assert m, l
+        decoded.setdefault(int(m.group(1)), set()).add(m.group(2))
+    for c in range(n_ch):
+        assert "".join(str(int(b)) for b in msgs[c]) in decoded.get(c, set()), c       # every stream's ping decoded, the stalled one too
+    # real-time behaviour: the run lasts about as long as the slowest stream's data (7 hops + the stall), not longer
+    assert wall < 0.216 * n_hops + 0.75 + 3.0, wall
+    m = re.search(r"(\d+) batches, (\d+) stream hops, (\d+) late, worst latency (\d+) ms", err)
+    assert m, err[-1500:]
+    batches, hops, late, worst = map(int, m.groups())
+    assert hops == n_ch * (n_hops + 1)                      # nothing dropped
+    assert batches > n_hops + 1                             # the stalled stream was served in batches of its own
+    assert late == 0 and worst <= 210, err[-1500:]          # no stream waited on the stalled one beyond the soft limit
