@@ -298,8 +298,13 @@ def run_worker(args) -> int:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * cand_per_step * args.steps / elapsed
         dom = max((n for n in T_NAMES), key=lambda n: stage[n][0])
-        dom_ms = stage[dom][0]
-        achieved = B_ALG_PER_CANDIDATE * cand_per_step / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # stage times are per STEP; softbits/index/ldpc are launched once per channel block (blocked staging), so one launch
+        # of the dominant kernel covers cand_per_step / launches candidates and lasts step_ms / launches on average
+        llr_block = getattr(be, "llr_block", channels) or channels
+        launches = -(-channels // llr_block) if dom in ("softbits", "index", "ldpc") else 1
+        dom_ms = stage[dom][0] / launches
+        cand_per_launch = cand_per_step / launches
+        achieved = B_ALG_PER_CANDIDATE * cand_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # Static PMC counters (separate rocprofv3 --pmc passes, committed under profiles/): used only when they were
         # collected on exactly these kernel sources and this workload; labelled with their origin.
         traffic, valu, static = None, None, None
@@ -334,7 +339,8 @@ def run_worker(args) -> int:
                        "real_time_channels": value / be.K / (12000.0 / 2592.0)},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,
-                         "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_step, "avg_launch_ms": dom_ms,
+                         "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_launch, "avg_launch_ms": dom_ms, "launches_per_step": launches,
+                         "candidates_per_launch": cand_per_launch,
                          "note": "path is VALU/LDS-bound (SURVEY.md 8d); HBM fraction reported as measured"},
             "valu_issue": valu,
             "stage_ms": {n: round(stage[n][0], 4) for n in T_NAMES},

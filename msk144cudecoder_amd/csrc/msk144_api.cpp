@@ -306,12 +306,16 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
         for(int k = 0; k < kSyncTaps; k++) cb[k] = make_float2(h->tpl.re[k], h->tpl.im[k]);
         ok = ok && hipMemcpy(h->d_cb42, cb, sizeof(cb), hipMemcpyHostToDevice) == hipSuccess;
     }
-    ok = ok && hipMemset(st.dec_flag, 0, ck) == hipSuccess;
-    ok = ok && hipMemset(st.n_idx, 0, sizeof(int32_t) * st.channels) == hipSuccess;
-    ok = ok && hipMemset(st.dec_count, 0, sizeof(int32_t) * st.channels) == hipSuccess;
-    ok = ok && hipMemset(st.result_count, 0, sizeof(int32_t)) == hipSuccess;
-    ok = ok && hipMemset(st.pos, 0, ck * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(st.nbadsync, 0, ck * sizeof(int32_t)) == hipSuccess;
+    // initial state on the handle's own (non-blocking) stream, which does not synchronise with the null stream; create
+    // returns only after these have completed
+    hipStream_t s0 = h->own_stream;
+    ok = ok && hipMemsetAsync(st.dec_flag, 0, ck, s0) == hipSuccess;
+    ok = ok && hipMemsetAsync(st.n_idx, 0, sizeof(int32_t) * st.channels, s0) == hipSuccess;
+    ok = ok && hipMemsetAsync(st.dec_count, 0, sizeof(int32_t) * st.channels, s0) == hipSuccess;
+    ok = ok && hipMemsetAsync(st.result_count, 0, sizeof(int32_t), s0) == hipSuccess;
+    ok = ok && hipMemsetAsync(st.pos, 0, ck * sizeof(uint32_t), s0) == hipSuccess;
+    ok = ok && hipMemsetAsync(st.nbadsync, 0, ck * sizeof(int32_t), s0) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s0) == hipSuccess;
 
     if(ok && params->read_mode == 1 && params->analytic_method == 1)
     {
@@ -628,7 +632,8 @@ int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candi
     HIP_TRY(h, hipMemcpy(st.xb + off, xb.data(), K * 4, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(st.nbadsync + off, nbad.data(), K * 4, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(st.llr + off * kCodeBits, llr.data(), K * kCodeBits * 4, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemset(st.dec_flag + off, 0, K));
+    HIP_TRY(h, hipMemsetAsync(st.dec_flag + off, 0, K, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MSK144_OK;
 }
 

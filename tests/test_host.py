@@ -168,3 +168,67 @@ def test_decode_cache_quirk_vs_strict(H):
     assert _post(H, t, [(1500.0, 1, 0, 0, bad), (1510.0, 1, 0, 0, m2)], quirk=1) == []
     assert len(_post(H, t, [(1500.0, 1, 0, 0, bad), (1510.0, 1, 0, 0, m2)], quirk=0)) == 1
     H.msk144host_table_free(t)
+
+
+def test_unpack77_against_the_published_field_arithmetic(H):
+    """Vectors assembled HERE from the published 77-bit field definitions (Franke/Somerville/Taylor, "The FT4 and FT8 Communication
+    Protocols", QEX Jul/Aug 2020, and the WSJT-X User Guide's ft8code examples) with plain integer arithmetic - not through
+    tests/pack77.py - so the text layer is checked against numbers the packer did not produce:
+      c28: tokens DE=0 QRZ=1 CQ=2; then 2^22 hash values; standard calls from NTOKENS + MAX22 = 2063592 + 4194304 on, mixed radix
+           37*36*10*27*27*27 over " 0-9A-Z" / "0-9A-Z" / "0-9" / " A-Z" x3 with the digit in third place;
+      g15: 4-character grid = ((A*18 + B)*10 + c)*10 + d; 32400 + 1..4 = blank/RRR/RR73/73; 32400 + 35 + report otherwise;
+      free text: 13 characters base 42 over " 0-9A-Z+-./?", 71 bits; telemetry: 18 hex digits, 71 bits.
+    K1ABC -> ' K1ABC' -> ((((0*36+20)*10+1)*27+1)*27+2)*27+3 = 3957069, + 6257896 = 10214965 = 0x9BDE35, the c28 printed for K1ABC
+    in the User Guide's `ft8code "K1ABC W9XYZ EN37"` example (bits 0000100110111101111000110101)."""
+    t = H.msk144host_table_new()
+
+    def bits(value, n):
+        return [(value >> (n - 1 - i)) & 1 for i in range(n)]
+
+    A1, A2, A3, A4 = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ", "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ", "0123456789", " ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+
+    def c28(call6):   # six characters, digit third
+        n = A1.index(call6[0])
+        n = n * 36 + A2.index(call6[1])
+        n = n * 10 + A3.index(call6[2])
+        for ch in call6[3:]:
+            n = n * 27 + A4.index(ch)
+        return n + 2063592 + 4194304
+
+    def grid4(g):
+        return ((("ABCDEFGHIJKLMNOPQR".index(g[0]) * 18 + "ABCDEFGHIJKLMNOPQR".index(g[1])) * 10 + int(g[2])) * 10 + int(g[3]))
+
+    assert c28(" K1ABC") == 10214965 == 0x9BDE35
+    assert "".join(map(str, bits(c28(" K1ABC"), 28))) == "0000100110111101111000110101"
+    assert grid4("FN42") == 10342
+
+    def std(n28a, n28b, r, g15, i3=1):
+        return bits(n28a, 28) + [0] + bits(n28b, 28) + [0] + [r] + bits(g15, 15) + bits(i3, 3)
+
+    k1abc, w9xyz = c28(" K1ABC"), c28(" W9XYZ")
+    cases = [
+        (std(2, k1abc, 0, grid4("FN42")), "CQ K1ABC FN42"),
+        (std(k1abc, w9xyz, 0, grid4("EN37")), "K1ABC W9XYZ EN37"),
+        (std(w9xyz, k1abc, 0, 32400 + 35 - 11), "W9XYZ K1ABC -11"),
+        (std(k1abc, w9xyz, 1, 32400 + 35 - 9), "K1ABC W9XYZ R-09"),
+        (std(w9xyz, k1abc, 0, 32400 + 2), "W9XYZ K1ABC RRR"),
+        (std(k1abc, w9xyz, 0, 32400 + 3), "K1ABC W9XYZ RR73"),
+        (std(k1abc, w9xyz, 0, 32400 + 4), "K1ABC W9XYZ 73"),
+        (std(0, k1abc, 0, 32400 + 1), "DE K1ABC"),
+        (std(1, c28("PA9XYZ"), 0, grid4("JO22")), "QRZ PA9XYZ JO22"),
+    ]
+    # free text "TNX BOB 73 GL": 13 characters right-justified in the 13-character field, base 42
+    alpha = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ+-./?"
+    txt = "TNX BOB 73 GL".rjust(13)
+    n71 = 0
+    for ch in txt:
+        n71 = n71 * 42 + alpha.index(ch)
+    assert n71 < (1 << 71)
+    cases.append((bits(n71, 71) + bits(0, 3) + bits(0, 3), "TNX BOB 73 GL"))
+    # telemetry 123456789ABCDEF012: 18 hex digits = 72 bits of which the top one is zero -> 71 bits, n3 = 5, i3 = 0
+    cases.append((bits(int("123456789ABCDEF012", 16), 71) + bits(5, 3) + bits(0, 3), "123456789ABCDEF012"))
+    for b77, want in cases:
+        assert len(b77) == 77
+        ok, text = _decode(H, t, b77)
+        assert ok and text == want, (text, want)
+    H.msk144host_table_free(t)
