@@ -46,14 +46,7 @@ constexpr int kChunk = 128;                                   // positions per w
 constexpr int kChunksPerSlice = kSlicePositions / kChunk;     // 2
 constexpr int kChunks = kScanPositions / kChunk;              // 42
 constexpr int kWrapPad = kSyncTaps - 1;
-constexpr int kStream = kOutPerThread + kSyncTaps - 1;        // 50 samples feed 9 outputs
 static_assert(kScanThreads % 64 == 0 && kScanThreads * kOutPerThread == kWindowSamples, "one in-place pass");
-
-// cb42[k] = (sign_re(k) * pp[k % 12], sign_im(k) * pp[(k + 6) % 12])   (msk_context.cuh:188-196)
-constexpr int tap_re_pp(int k) { return k % 12; }
-constexpr int tap_im_pp(int k) { return (k + 6) % 12; }
-constexpr int tap_re_sign(int k) { return kSync8Pm[2 * (k / 12) + 1]; }
-constexpr int tap_im_sign(int k) { return kSync8Pm[2 * ((k + 6) / 12)]; }
 
 struct ScanArgs
 {
@@ -62,52 +55,6 @@ struct ScanArgs
     int total_tiles;
     int tiles_per_xcd;
 };
-
-// One tap of one output, everything about the tap resolved at compile time:
-// conj(x)*cb[k] = (x.x*re + x.y*im) + i(x.x*im - x.y*re), re = +-pp[k%12], im = +-pp[(k+6)%12].
-template<int J, int R>
-__device__ __forceinline__ void tap_mac(const float2 x, float (&cr)[kOutPerThread], float (&ci)[kOutPerThread], const float (&pp)[12])
-{
-    constexpr int k = J - R;
-    if constexpr(k >= 0 && k < kSyncTaps)
-    {
-        if constexpr(tap_re_pp(k) != 0)
-        {
-            const float re = pp[tap_re_pp(k)];
-            if constexpr(tap_re_sign(k) > 0)
-            {
-                cr[R] = fmaf(x.x, re, cr[R]);
-                ci[R] = fmaf(-x.y, re, ci[R]);
-            }
-            else
-            {
-                cr[R] = fmaf(-x.x, re, cr[R]);
-                ci[R] = fmaf(x.y, re, ci[R]);
-            }
-        }
-        if constexpr(tap_im_pp(k) != 0)
-        {
-            const float im = pp[tap_im_pp(k)];
-            if constexpr(tap_im_sign(k) > 0)
-            {
-                cr[R] = fmaf(x.y, im, cr[R]);
-                ci[R] = fmaf(x.x, im, ci[R]);
-            }
-            else
-            {
-                cr[R] = fmaf(-x.y, im, cr[R]);
-                ci[R] = fmaf(-x.x, im, ci[R]);
-            }
-        }
-    }
-}
-
-template<int J, int... R>
-__device__ __forceinline__ void feed_sample(const float2 x, float (&cr)[kOutPerThread], float (&ci)[kOutPerThread], const float (&pp)[12],
-                                            std::integer_sequence<int, R...>)
-{
-    (tap_mac<J, R>(x, cr, ci, pp), ...);
-}
 
 // LDS pointer kept volatile so that the 50 sample loads stay ds_read_b64 (2 LDS cycles each); merged into
 // ds_read2_b64 the same bytes take twice as long (MI355X_MICROARCH.md, LDS table).
@@ -119,11 +66,94 @@ __device__ __forceinline__ float2 as_float2(v2f v)
     return make_float2(v.x, v.y);
 }
 
-template<int... J>
-__device__ __forceinline__ void stream_all(lds_f2_ptr xs, float (&cr)[kOutPerThread], float (&ci)[kOutPerThread], const float (&pp)[12],
-                                           std::integer_sequence<int, J...>)
+// ---- correlation by pulse decomposition ----
+// The 42-tap template is seven half-sine pulses of 12 samples, alternating between the I and the Q rail and offset by
+// half a pulse (msk_context.cuh:188-196): with the half-pulse sums
+//     A[m] = sum_{d<6} x[m+d] * pp[d]        B[m] = sum_{d<6} x[m+d] * pp[6+d]        P[m] = A[m] + B[m+6]  (a full pulse)
+//     sum_k x[n+k] * cbi[k] = s1 P[n] + s3 P[n+12] + s5 P[n+24] + s7 A[n+36]    =: R
+//     sum_k x[n+k] * cbq[k] = s0 B[n] + s2 P[n+6]  + s4 P[n+18] + s6 P[n+30]    =: Q
+//     C[n] = sum_k conj(x[n+k]) (cbi[k] + i cbq[k]) = (R.x + Q.y, Q.x - R.y)
+// everything C[n] needs lives at offsets n + 6j.  A thread therefore owns nine outputs SPACED BY SIX, n = n0 + 6r: they share
+// the fifteen half-pulse pairs at n0 + 6i, each built from its own six samples, so the 90 samples a thread streams are
+// used exactly once per rail: 165 multiply-adds and 77 adds of complex values per thread instead of 693 + 72 with one
+// 42-tap sum per output (-2.4 k of the kernel's 8.7 k issue cycles per wave).  Same linear form, different association:
+// ~1e-6 relative on xb, as before.  Thread t = 6q + c owns n0 = 54 q + c.
+constexpr int kPulseHalf = 6;
+constexpr int kHalfPulses = kOutPerThread + 6;  // 15 half-pulse positions feed 9 outputs
+constexpr int kStream = kHalfPulses * kPulseHalf;  // 90 samples
+constexpr int kOutSpan = kOutPerThread * kPulseHalf;  // 54 consecutive outputs per group of 6 threads
+static_assert(kWindowSamples % kOutSpan == 0 && (kWindowSamples / kOutSpan) * kPulseHalf == kScanThreads, "thread -> (block of 54, residue) map");
+static_assert(kOutSpan * (kWindowSamples / kOutSpan - 1) + kPulseHalf - 1 + kStream - 1 < kWindowSamples + kWrapPad, "the last thread's stream stays inside the wrap pad");
+
+template<int kSign>
+__device__ __forceinline__ void acc_signed(float2& acc, const float2 v)
 {
-    (feed_sample<J>(as_float2(xs[J]), cr, ci, pp, std::make_integer_sequence<int, kOutPerThread>{}), ...);
+    if constexpr(kSign > 0)
+    {
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+    else
+    {
+        acc.x -= v.x;
+        acc.y -= v.y;
+    }
+}
+
+__device__ __forceinline__ void correlate_pulses(lds_f2_ptr xs, const float (&pp)[12], float2 (&c)[kOutPerThread])
+{
+    float2 racc[kOutPerThread], qacc[kOutPerThread];
+#pragma unroll
+    for(int r = 0; r < kOutPerThread; r++)
+    {
+        racc[r] = make_float2(0.0f, 0.0f);
+        qacc[r] = make_float2(0.0f, 0.0f);
+    }
+    float2 a_prev = make_float2(0.0f, 0.0f);
+    // Left alone, the scheduler clusters the 90 loads and sinks the arithmetic behind them (114 VGPRs; capping the registers
+    // spills, sched_barrier makes it worse).  The empty asm at the end of every half-pulse takes A_i and B_i as read-write
+    // operands together with `off`, an opaque zero in the next loads' address: the half-pulse's arithmetic must be complete -
+    // its six samples dead - before the loads of the next one can issue.
+    int off = 0;
+#pragma unroll
+    for(int i = 0; i < kHalfPulses; i++)
+    {
+        float2 x[kPulseHalf];
+#pragma unroll
+        for(int d = 0; d < kPulseHalf; d++) x[d] = as_float2(xs[off + i * kPulseHalf + d]);
+        // A_i (pp[0] = sin 0 = 0: five terms) and B_i
+        float2 av = make_float2(x[1].x * pp[1], x[1].y * pp[1]);
+        float2 bv = make_float2(x[0].x * pp[6], x[0].y * pp[6]);
+#pragma unroll
+        for(int d = 2; d < kPulseHalf; d++)
+        {
+            av.x = fmaf(x[d].x, pp[d], av.x);
+            av.y = fmaf(x[d].y, pp[d], av.y);
+        }
+#pragma unroll
+        for(int d = 1; d < kPulseHalf; d++)
+        {
+            bv.x = fmaf(x[d].x, pp[kPulseHalf + d], bv.x);
+            bv.y = fmaf(x[d].y, pp[kPulseHalf + d], bv.y);
+        }
+        if(i < kOutPerThread) acc_signed<kSync8Pm[0]>(qacc[i], bv);                                   // Q_i  += s0 B_i
+        if(i >= 1)
+        {
+            const int j = i - 1;                                                                       // P_j = A_j + B_(j+1)
+            const float2 pv = make_float2(a_prev.x + bv.x, a_prev.y + bv.y);
+            if(j < kOutPerThread) acc_signed<kSync8Pm[1]>(racc[j], pv);                                // R_j     += s1 P_j
+            if(j >= 2 && j - 2 < kOutPerThread) acc_signed<kSync8Pm[3]>(racc[j - 2], pv);              // R_(j-2) += s3 P_j
+            if(j >= 4 && j - 4 < kOutPerThread) acc_signed<kSync8Pm[5]>(racc[j - 4], pv);              // R_(j-4) += s5 P_j
+            if(j >= 1 && j - 1 < kOutPerThread) acc_signed<kSync8Pm[2]>(qacc[j - 1], pv);              // Q_(j-1) += s2 P_j
+            if(j >= 3 && j - 3 < kOutPerThread) acc_signed<kSync8Pm[4]>(qacc[j - 3], pv);              // Q_(j-3) += s4 P_j
+            if(j >= 5 && j - 5 < kOutPerThread) acc_signed<kSync8Pm[6]>(qacc[j - 5], pv);              // Q_(j-5) += s6 P_j
+        }
+        if(i >= 6) acc_signed<kSync8Pm[7]>(racc[i - 6], av);                                           // R_(i-6) += s7 A_i
+        a_prev = av;
+        asm volatile("" : "+v"(off), "+v"(av.x), "+v"(av.y), "+v"(bv.x), "+v"(bv.y));
+    }
+#pragma unroll
+    for(int r = 0; r < kOutPerThread; r++) c[r] = make_float2(racc[r].x + qacc[r].y, qacc[r].x - racc[r].y);
 }
 
 template<int kD>
@@ -162,21 +192,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     }
     __syncthreads();
 
-    // ---- 2. C[n0..n0+8], n0 = 9*tid: stream 50 samples, conj(x)*cb = (x.x*re + x.y*im) + i(x.x*im - x.y*re) ----
+    // ---- 2. C[n0 + 6r], r = 0..8, by pulse decomposition (correlate_pulses); C then overwrites the window in place ----
     {
-        float cr[kOutPerThread], ci[kOutPerThread];
-#pragma unroll
-        for(int r = 0; r < kOutPerThread; r++)
-        {
-            cr[r] = 0.0f;
-            ci[r] = 0.0f;
-        }
-        lds_f2_ptr xs = (lds_f2_ptr)(s_buf + tid * kOutPerThread);
-        stream_all(xs, cr, ci, a.pp, std::make_integer_sequence<int, kStream>{});
+        const int q = tid / kPulseHalf;
+        const int n0 = kOutSpan * q + (tid - q * kPulseHalf);
+        float2 c[kOutPerThread];
+        correlate_pulses((lds_f2_ptr)(s_buf + n0), a.pp, c);
         __syncthreads();  // every thread has read its samples: C may overwrite the window
-        float2* __restrict__ cs = s_buf + tid * kOutPerThread;
 #pragma unroll
-        for(int r = 0; r < kOutPerThread; r++) cs[r] = make_float2(cr[r], ci[r]);
+        for(int r = 0; r < kOutPerThread; r++) s_buf[n0 + kPulseHalf * r] = c[r];
     }
     __syncthreads();
 
