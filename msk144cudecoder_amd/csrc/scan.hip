@@ -214,20 +214,57 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     for(int chunk = wave; chunk < kChunks; chunk += kScanWaves)
     {
         float2 ca[2][kFrames], cb[2][kFrames];
+        // Ring addresses of the 4*frames samples.  The wrap decision (pos + offset >= 5184) is the same for all 128 positions
+        // of a chunk unless one of the 13 wrap points falls inside it (12 of the 42 chunks): the common case is one scalar
+        // offset per frame/partner and a single v_add per load; the per-lane add/sub/min chain (72 VALU instructions per
+        // chunk) is kept for the chunks that need it.
+        const int chunk_u = __builtin_amdgcn_readfirstlane(chunk);
+        const uint32_t p0 = static_cast<uint32_t>(chunk_u) * kChunk;  // first position of the chunk, 0..5248
+        uint32_t base_a[kFrames], base_b[kFrames];
+        bool uniform = p0 + (kChunk - 1) < static_cast<uint32_t>(kWindowSamples) || p0 >= static_cast<uint32_t>(kWindowSamples);
+        const uint32_t q0 = p0 >= static_cast<uint32_t>(kWindowSamples) ? p0 - kWindowSamples : p0;
 #pragma unroll
-        for(int j = 0; j < 2; j++)
+        for(int m = 0; m < kFrames; m++)
         {
-            const uint32_t pos = chunk * kChunk + j * 64 + lane;  // 0..5375
-            const uint32_t q8 = (pos >= static_cast<uint32_t>(kWindowSamples) ? pos - kWindowSamples : pos) * 8u;
+            uint32_t ta = q0 + static_cast<uint32_t>(kFrameSamples * m);
+            if(ta >= static_cast<uint32_t>(kWindowSamples)) ta -= kWindowSamples;
+            uint32_t tb = ta + kSecondSyncSample;
+            if(tb >= static_cast<uint32_t>(kWindowSamples)) tb -= kWindowSamples;
+            uniform = uniform && ta + (kChunk - 1) < static_cast<uint32_t>(kWindowSamples) && tb + (kChunk - 1) < static_cast<uint32_t>(kWindowSamples);
+            base_a[m] = ta * 8u;
+            base_b[m] = tb * 8u;
+        }
+        if(uniform)
+        {
 #pragma unroll
-            for(int m = 0; m < kFrames; m++)
+            for(int j = 0; j < 2; j++)
             {
-                const uint32_t a8 = q8 + static_cast<uint32_t>(kFrameSamples * 8 * m);
-                const uint32_t ia = min(a8, a8 - kN8);  // a8 mod ring (unsigned wrap trick)
-                const uint32_t b8 = ia + kSecondSyncSample * 8u;
-                const uint32_t ib = min(b8, b8 - kN8);
-                ca[j][m] = *reinterpret_cast<const float2*>(cbytes + ia);
-                cb[j][m] = *reinterpret_cast<const float2*>(cbytes + ib);
+                const uint32_t l8 = static_cast<uint32_t>(j * 64 + lane) * 8u;
+#pragma unroll
+                for(int m = 0; m < kFrames; m++)
+                {
+                    ca[j][m] = *reinterpret_cast<const float2*>(cbytes + (l8 + base_a[m]));
+                    cb[j][m] = *reinterpret_cast<const float2*>(cbytes + (l8 + base_b[m]));
+                }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for(int j = 0; j < 2; j++)
+            {
+                const uint32_t pos = chunk * kChunk + j * 64 + lane;  // 0..5375
+                const uint32_t q8 = (pos >= static_cast<uint32_t>(kWindowSamples) ? pos - kWindowSamples : pos) * 8u;
+#pragma unroll
+                for(int m = 0; m < kFrames; m++)
+                {
+                    const uint32_t a8 = q8 + static_cast<uint32_t>(kFrameSamples * 8 * m);
+                    const uint32_t ia = min(a8, a8 - kN8);  // a8 mod ring (unsigned wrap trick)
+                    const uint32_t b8 = ia + kSecondSyncSample * 8u;
+                    const uint32_t ib = min(b8, b8 - kN8);
+                    ca[j][m] = *reinterpret_cast<const float2*>(cbytes + ia);
+                    cb[j][m] = *reinterpret_cast<const float2*>(cbytes + ib);
+                }
             }
         }
         float sr[2] = {0.0f, 0.0f}, si[2] = {0.0f, 0.0f};
