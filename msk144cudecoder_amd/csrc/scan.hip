@@ -43,7 +43,6 @@ constexpr int kOutPerThread = 9;
 constexpr int kScanThreads = kWindowSamples / kOutPerThread;  // 576 = 9 waves: one pass, in-place C
 constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kChunk = 128;                                   // positions per wave work unit
-constexpr int kChunksPerSlice = kSlicePositions / kChunk;     // 2
 constexpr int kChunks = kScanPositions / kChunk;              // 42
 constexpr int kWrapPad = kSyncTaps - 1;
 static_assert(kScanThreads % 64 == 0 && kScanThreads * kOutPerThread == kWindowSamples, "one in-place pass");

@@ -12,8 +12,8 @@
 // (softbits_kernel.cuh:158-177: I bits 12j..12j+11, Q bits 12j-6..12j+5), so its 12-tap sum starts in
 // the lane of group u-1 (taps pp[0..5]), hops one lane with a DPP wave shift and finishes in lane
 // u%64 with taps pp[6..11] - the reference's tap order, and softbit u ends up in lane u%64 of slot u/64.
-// From there the two 144-term sums reproduce sum_reduction_two_cycles on five 32-lane warps
-// (sum_reduction.cuh:14-44): ((w0+w1)+(w2+w3))+w4, with DPP adds instead of shuffles.
+// From there the two 144-term sums (softbits_kernel.cuh:186-194) are one per-lane add over the three slots plus a
+// single cross-lane reduction carrying both sums (sum_reduction.cuh:14-44 replaced by two interleaved DPP chains).
 // The phase rotation uses conj(s)/|s| instead of atan2f + sincosf (same unit vector to ~1 ulp); the
 // 84-term phase sum is accumulated per lane and then across lanes (order differs from the reference's
 // 42->32->16 tree: ~1e-7 relative on a rotation angle).
@@ -50,21 +50,6 @@ template<int kCtrl>
 __device__ __forceinline__ float dpp_add(float v)
 {
     return f32_add(v, dpp_f32<kCtrl>(v));
-}
-
-// sums of the two 32-lane halves in the reference's shuffle order (offsets 1,2,4,8,16)
-__device__ __forceinline__ void half_sums(float v, float& lo, float& hi)
-{
-    v = row_sum_f32(v);
-    lo = f32_add(readlane_f32(v, 0), readlane_f32(v, 16));
-    hi = f32_add(readlane_f32(v, 32), readlane_f32(v, 48));
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-    float lo, hi;
-    half_sums(v, lo, hi);
-    return lo + hi;
 }
 
 __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs a)
@@ -183,8 +168,9 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
                 pi = fmaf(-acc[0][t].x, cbi, pi);
             }
         }
-        const float sre = wave_sum(pr);
-        const float sim = wave_sum(pi);
+        row_sum2_f32(pr, pi);
+        const float sre = f32_add(f32_add(readlane_f32(pr, 0), readlane_f32(pr, 16)), f32_add(readlane_f32(pr, 32), readlane_f32(pr, 48)));
+        const float sim = f32_add(f32_add(readlane_f32(pi, 0), readlane_f32(pi, 16)), f32_add(readlane_f32(pi, 32), readlane_f32(pi, 48)));
         // cfac = conj(exp(i*atan2(im,re))) = (re, -im)/|s|
         float cr = 1.0f, ci = 0.0f;
         {
@@ -238,21 +224,20 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
             soft[s] = (s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) ? 0.0f : sb;
         }
 
-        // ---- normalisation (softbits_kernel.cuh:186-201), warp sums w0..w4 in the reference's order ----
-        float w_s[5], w_q[5];
-#pragma unroll
-        for(int s = 0; s < kSlots; s++)
+        // ---- normalisation (softbits_kernel.cuh:186-201) ----
+        // sum and sum of squares of the 144 softbits: per lane over its three slots first, then ONE cross-lane reduction
+        // for both (two interleaved DPP chains, row sums combined as ((r0+r1)+(r2+r3))).  The reference's
+        // sum_reduction_two_cycles order (five 32-lane warp sums) was reproduced term by term until round 2 at the price of
+        // six separate reductions; a different association moves sav/s2av by ~1e-7 relative, i.e. every LLR by ~1e-7 of
+        // itself - four orders inside the 1e-3 tolerance and below what sincos/sqrt differences already contribute (8e-6).
+        float sum_sav, sum_s2av;
         {
-            float lo, hi;
-            half_sums(soft[s], lo, hi);
-            w_s[2 * s] = lo;
-            if(s < 2) w_s[2 * s + 1] = hi;
-            half_sums(f32_mul(soft[s], soft[s]), lo, hi);
-            w_q[2 * s] = lo;
-            if(s < 2) w_q[2 * s + 1] = hi;
+            float t = f32_add(f32_add(soft[0], soft[1]), soft[2]);
+            float q = fmaf(soft[2], soft[2], fmaf(soft[1], soft[1], f32_mul(soft[0], soft[0])));
+            row_sum2_f32(t, q);
+            sum_sav = f32_add(f32_add(readlane_f32(t, 0), readlane_f32(t, 16)), f32_add(readlane_f32(t, 32), readlane_f32(t, 48)));
+            sum_s2av = f32_add(f32_add(readlane_f32(q, 0), readlane_f32(q, 16)), f32_add(readlane_f32(q, 32), readlane_f32(q, 48)));
         }
-        const float sum_sav = f32_add(f32_add(f32_add(w_s[0], w_s[1]), f32_add(w_s[2], w_s[3])), w_s[4]);
-        const float sum_s2av = f32_add(f32_add(f32_add(w_q[0], w_q[1]), f32_add(w_q[2], w_q[3])), w_q[4]);
         const float sav = div_by_const<144>(sum_sav);    // correctly rounded, like the reference's division
         const float s2av = div_by_const<144>(sum_s2av);
         const float ssig = f32_sqrt(f32_sub(s2av, f32_mul(sav, sav)));

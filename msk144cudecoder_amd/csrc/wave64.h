@@ -129,6 +129,30 @@ __device__ __forceinline__ float row_sum_f32(float v)
     return r;
 }
 
+// row_sum_f32 for two independent values at once: the two chains interleave, one s_nop 0 per step completes the two wait
+// states a DPP read needs after the VALU write of its source.
+__device__ __forceinline__ void row_sum2_f32(float& a, float& b)
+{
+    float ra, rb;
+    asm volatile("s_nop 4\n\t"
+                 "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "=&v"(ra), "=&v"(rb)
+                 : "v"(a), "v"(b));
+    a = ra;
+    b = rb;
+}
+
 __device__ __forceinline__ float readlane_f32(float v, int lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));

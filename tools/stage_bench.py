@@ -24,7 +24,7 @@ if args.lib:
     hd._lib = hd.load_library(os.path.abspath(args.lib))
 bits = {"scan": hd.STAGE_SCAN, "softbits": hd.STAGE_SOFTBITS, "index": hd.STAGE_INDEX, "ldpc": hd.STAGE_LDPC, "collect": hd.STAGE_COLLECT}
 wins, _ = bench.make_inputs(0, args.channels)
-with hd.HipDecoder(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=args.threshold, channels=args.channels, max_results=1 << 20) as d:
+with hd.HipDecoder(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=args.threshold, channels=args.channels, max_results=1 << 20, llr_block_channels=args.channels) as d:
     d.submit_audio(wins[1])
     d.decode()
     n0 = d.result_count()
