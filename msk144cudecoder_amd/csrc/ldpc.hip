@@ -198,7 +198,10 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             const uint64_t hi = __ballot(cw[1]);
 
             // 38 parity checks: lane c < 38 evaluates check c
-            const int par = (__popcll(lo & hlo) + __popcll(hi & hhi)) & 1;
+            // parity of popcount(cw & H_row): fold the four masked dwords with XOR first (full-rate ops) and count once
+            // (v_bcnt is half rate): 9 instead of 13 instructions
+            const uint64_t masked = (lo & hlo) ^ (hi & hhi);
+            const int par = __popc(static_cast<uint32_t>(masked) ^ static_cast<uint32_t>(masked >> 32)) & 1;
             const uint64_t syndrome = __ballot(par != 0) & ((1ull << kChecks) - 1ull);
 
             if(syndrome == 0)

@@ -118,11 +118,7 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
 
         // ---- fold the averaged frames (softbits_kernel.cuh:59-82) ----
-        v2f acc[kSlots][kGroup];  // (re, im) pairs: the fold adds are packed v_pk_add_f32
-#pragma unroll
-        for(int s = 0; s < kSlots; s++)
-#pragma unroll
-            for(int t = 0; t < kGroup; t++) acc[s][t] = v2f{0.0f, 0.0f};
+        v2f acc[kSlots][kGroup];  // (re, im) pairs
         // byte offset of this lane's group in each slot, frame 0.  Slot 2 only has groups 128..143: lanes
         // >= 16 re-read group 143 (harmless, their results are discarded) so the loop stays convergent.
         uint32_t slot8[kSlots];
@@ -133,17 +129,29 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
             const int l = lane < last ? lane : last;
             slot8[s] = (pos + static_cast<uint32_t>(kGroup) * (l + 64 * s)) * 8u;
         }
-        for(int m = 0; m < kPatternBits; m++)
+        // volatile: keeps these as six ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 the same
+        // bytes take twice as long (MI355X_MICROARCH.md, LDS table)
+        typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+        // frame 0 is part of every pattern (msk_context.cuh:231-238): its samples ARE the initial sums (no add to zero)
+#pragma unroll
+        for(int s = 0; s < kSlots; s++)
+        {
+            const uint32_t i8 = min(slot8[s], slot8[s] - kN8);
+            lds_v2f_ptr run = (lds_v2f_ptr)(xbytes + i8);
+#pragma unroll
+            for(int t = 0; t < kGroup; t++) acc[s][t] = run[t];
+        }
+        for(int m = 1; m < kPatternBits; m++)
         {
             if(!kPatternMask[p][m]) continue;  // wave-uniform
 #pragma unroll
             for(int s = 0; s < kSlots; s++)
             {
                 const uint32_t a8 = slot8[s] + static_cast<uint32_t>(kFrameSamples * m * 8);  // < 2 * ring
-                const uint32_t i8 = min(a8, a8 - kN8);
-                // volatile: keeps these as six ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 the same
-                // bytes take twice as long (MI355X_MICROARCH.md, LDS table)
-                typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+                uint32_t i8 = min(a8, a8 - kN8);
+                // one slot's six samples in flight at a time (12 VGPRs): with all 18 loads of a frame hoisted above the adds
+                // the kernel needs 76 VGPRs; at 64 two 16-wave workgroups fill all 32 wave slots of a CU
+                if(s > 0) asm volatile("" : "+v"(i8) : "v"(acc[s - 1][kGroup - 1]));
                 lds_v2f_ptr run = (lds_v2f_ptr)(xbytes + i8);
 #pragma unroll
                 for(int t = 0; t < kGroup; t++) acc[s][t] += run[t];
@@ -194,9 +202,8 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
         // re = fr*cr - fi*ci, im = fr*ci + fi*cr: pick the coefficient pair per lane once instead of
         // selecting per sample.
         const float a_r = odd ? ci : cr, a_i = odd ? cr : -ci;   // va = fr*a_r + fi*a_i
-        const float b_r = odd ? cr : ci, b_i = odd ? -ci : cr;   // vb = fr*b_r + fi*b_i
+        float b_r = odd ? cr : ci, b_i = odd ? -ci : cr;         // vb = fr*b_r + fi*b_i
         float start[kSlots], soft[kSlots];
-        float vb[kSlots][kGroup];
 #pragma unroll
         for(int s = 0; s < kSlots; s++)
         {
@@ -205,11 +212,13 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
             for(int t = 0; t < kGroup; t++)
             {
                 const float va = fmaf(acc[s][t].y, a_i, acc[s][t].x * a_r);
-                vb[s][t] = fmaf(acc[s][t].y, b_i, acc[s][t].x * b_r);
                 sb = fmaf(va, pp[t], sb);
             }
             start[s] = sb;
         }
+        // vb is formed only now, slot by slot, straight into the second half of the tap sum: keeping the 18 vb values of the
+        // first pass alive cost 12 VGPRs more than 8 waves per SIMD allow.  The empty asm makes the scheduler respect that order.
+        asm volatile("" : "+v"(b_r), "+v"(b_i) : "v"(start[0]), "v"(start[1]), "v"(start[2]));
 #pragma unroll
         for(int s = 0; s < kSlots; s++)
         {
@@ -220,7 +229,11 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
             if(lane == 0) in = edge;
             float sb = in;
 #pragma unroll
-            for(int t = 0; t < kGroup; t++) sb = fmaf(vb[s][t], pp[kGroup + t], sb);
+            for(int t = 0; t < kGroup; t++)
+            {
+                const float vb = fmaf(acc[s][t].y, b_i, acc[s][t].x * b_r);
+                sb = fmaf(vb, pp[kGroup + t], sb);
+            }
             soft[s] = (s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) ? 0.0f : sb;
         }
 
