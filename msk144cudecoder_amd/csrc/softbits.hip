@@ -52,9 +52,9 @@ __device__ __forceinline__ float dpp_add(float v)
     return f32_add(v, dpp_f32<kCtrl>(v));
 }
 
-__global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs a)
+__global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsArgs a)
 {
-    __shared__ float2 s_x[kWindowSamples + kRunPad + 3];
+    __shared__ __attribute__((aligned(16))) float2 s_x[kWindowSamples + kRunPad + 3];
 
     const int xcd = blockIdx.x & 7;
     const int tile = xcd * a.tiles_per_xcd + (blockIdx.x >> 3);
@@ -129,32 +129,86 @@ __global__ __launch_bounds__(kSbThreads) void softbits_kernel(const SoftbitsArgs
             const int l = lane < last ? lane : last;
             slot8[s] = (pos + static_cast<uint32_t>(kGroup) * (l + 64 * s)) * 8u;
         }
-        // volatile: keeps these as six ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 the same
-        // bytes take twice as long (MI355X_MICROARCH.md, LDS table)
+        // A lane reads its group's six samples (48 B).  With ds_read_b64 the 48-byte lane stride makes lanes l and l + 16 of a
+        // 32-lane access group share a bank pair (6*16 = 0 mod 32): a 2-way conflict on every read, 4 LDS cycles per sample
+        // pair and the largest single cost of this kernel.  ds_read_b128 services 16 lanes per cycle, and at this stride their
+        // sixteen 16-byte pieces tile all 64 banks exactly: conflict-free, 4 cycles per TWO samples.  It needs 16-byte
+        // alignment, which depends only on the parity of the candidate position (wave-uniform; group offsets 6g and frame
+        // offsets 864m are even): even -> three b128; odd -> b64, two b128, b64.  volatile keeps the compiler from re-merging.
+        typedef float v4f __attribute__((ext_vector_type(4)));
         typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+        typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
+        const bool pos_even = (pos & 1u) == 0u;
         // frame 0 is part of every pattern (msk_context.cuh:231-238): its samples ARE the initial sums (no add to zero)
-#pragma unroll
-        for(int s = 0; s < kSlots; s++)
+        if(pos_even)
         {
-            const uint32_t i8 = min(slot8[s], slot8[s] - kN8);
-            lds_v2f_ptr run = (lds_v2f_ptr)(xbytes + i8);
-#pragma unroll
-            for(int t = 0; t < kGroup; t++) acc[s][t] = run[t];
-        }
-        for(int m = 1; m < kPatternBits; m++)
-        {
-            if(!kPatternMask[p][m]) continue;  // wave-uniform
 #pragma unroll
             for(int s = 0; s < kSlots; s++)
             {
-                const uint32_t a8 = slot8[s] + static_cast<uint32_t>(kFrameSamples * m * 8);  // < 2 * ring
-                uint32_t i8 = min(a8, a8 - kN8);
-                // one slot's six samples in flight at a time (12 VGPRs): with all 18 loads of a frame hoisted above the adds
-                // the kernel needs 76 VGPRs; at 64 two 16-wave workgroups fill all 32 wave slots of a CU
-                if(s > 0) asm volatile("" : "+v"(i8) : "v"(acc[s - 1][kGroup - 1]));
-                lds_v2f_ptr run = (lds_v2f_ptr)(xbytes + i8);
+                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + min(slot8[s], slot8[s] - kN8));
+                const v4f q0 = q[0], q1 = q[1], q2 = q[2];
+                acc[s][0] = v2f{q0.x, q0.y};
+                acc[s][1] = v2f{q0.z, q0.w};
+                acc[s][2] = v2f{q1.x, q1.y};
+                acc[s][3] = v2f{q1.z, q1.w};
+                acc[s][4] = v2f{q2.x, q2.y};
+                acc[s][5] = v2f{q2.z, q2.w};
+            }
+            for(int m = 1; m < kPatternBits; m++)
+            {
+                if(!kPatternMask[p][m]) continue;  // wave-uniform
 #pragma unroll
-                for(int t = 0; t < kGroup; t++) acc[s][t] += run[t];
+                for(int s = 0; s < kSlots; s++)
+                {
+                    const uint32_t a8 = slot8[s] + static_cast<uint32_t>(kFrameSamples * m * 8);  // < 2 * ring
+                    const uint32_t i8 = min(a8, a8 - kN8);
+                    lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8);
+                    const v4f q0 = q[0], q1 = q[1], q2 = q[2];
+                    acc[s][0] += v2f{q0.x, q0.y};
+                    acc[s][1] += v2f{q0.z, q0.w};
+                    acc[s][2] += v2f{q1.x, q1.y};
+                    acc[s][3] += v2f{q1.z, q1.w};
+                    acc[s][4] += v2f{q2.x, q2.y};
+                    acc[s][5] += v2f{q2.z, q2.w};
+                }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for(int s = 0; s < kSlots; s++)
+            {
+                const uint32_t i8 = min(slot8[s], slot8[s] - kN8);
+                lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
+                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
+                acc[s][0] = r[0];
+                const v4f q0 = q[0], q1 = q[1];
+                acc[s][5] = r[5];
+                acc[s][1] = v2f{q0.x, q0.y};
+                acc[s][2] = v2f{q0.z, q0.w};
+                acc[s][3] = v2f{q1.x, q1.y};
+                acc[s][4] = v2f{q1.z, q1.w};
+            }
+            for(int m = 1; m < kPatternBits; m++)
+            {
+                if(!kPatternMask[p][m]) continue;  // wave-uniform
+#pragma unroll
+                for(int s = 0; s < kSlots; s++)
+                {
+                    const uint32_t a8 = slot8[s] + static_cast<uint32_t>(kFrameSamples * m * 8);  // < 2 * ring
+                    const uint32_t i8 = min(a8, a8 - kN8);
+                    lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
+                    lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
+                    const v2f x0 = r[0];
+                    const v4f q0 = q[0], q1 = q[1];
+                    const v2f x5 = r[5];
+                    acc[s][0] += x0;
+                    acc[s][1] += v2f{q0.x, q0.y};
+                    acc[s][2] += v2f{q0.z, q0.w};
+                    acc[s][3] += v2f{q1.x, q1.y};
+                    acc[s][4] += v2f{q1.z, q1.w};
+                    acc[s][5] += x5;
+                }
             }
         }
 
