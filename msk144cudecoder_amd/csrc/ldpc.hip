@@ -16,6 +16,7 @@
 // Work distribution: grid = (blocks per channel, channels); waves stride over the channel's index list
 // (idx/n_idx from index_kernel), so no host read of N_idx sits between the kernels
 // (the reference dereferences a device pointer on the host here, result_keeper.cuh:162).
+#include "ldpc_layout.h"
 #include "msk144_kernels.h"
 #include "wave64.h"
 
@@ -27,38 +28,61 @@ namespace
 
 constexpr int kLdpcThreads = 256;
 constexpr int kLdpcWaves = kLdpcThreads / 64;
-constexpr int kTStride = 40;  // T[slot][check] row stride (38 checks padded)
+constexpr int kTStride = kTileRowStride;  // T[slot][lane of check] row stride (ldpc_layout.h)
 
-// Edge tables derived at compile time from the check-major graph.
+// Edge tables derived at compile time from the check-major graph and the lane layout of ldpc_layout.h (bit -> lane, check ->
+// lane and first-edge order were annealed offline so that the edge-side scatter/gather through the tile is at most 2-way
+// conflicted: 9 instead of 18 extra LDS cycles per iteration and direction; 2-way costs a ds_write_b32 nothing).
 struct EdgeTables
 {
-    int8_t check[kCodeBits][kEdgesPerBit];  // edge k of bit n -> check, k ascending in check
-    int8_t slot[kCodeBits][kEdgesPerBit];   //               -> slot inside that check
-    uint64_t hlo[kChecks];                  // parity-check row as bit masks over cw[0..63], cw[64..127]
-    uint64_t hhi[kChecks];
-    uint8_t full[kChecks];                  // degree-11 checks (ldpc_context.cuh:160-163)
+    uint16_t cell[2][64][kEdgesPerBit];  // tile cell of the edge handled by instruction i of (half h, lane l)
+    uint64_t hlo[64];                    // parity-check row of the lane's check as masks over ballot(half 0), ballot(half 1)
+    uint64_t hhi[64];
+    uint8_t full[64];                    // the lane's check has 11 bits (ldpc_context.cuh:160-163)
+    uint8_t pos_of_bit[kCodeBits];       // codeword bit n sits at ballot position h*64 + lane
 };
 
 constexpr EdgeTables make_edge_tables()
 {
     EdgeTables t{};
+    for(int h = 0; h < 2; h++)
+        for(int l = 0; l < 64; l++) t.pos_of_bit[kBitOfLane[h][l]] = static_cast<uint8_t>(h * 64 + l);
     int cnt[kCodeBits] = {};
+    int8_t e_check[kCodeBits][kEdgesPerBit] = {};
+    int8_t e_slot[kCodeBits][kEdgesPerBit] = {};
+    for(int l = 0; l < 64; l++)
+    {
+        t.hlo[l] = 0;
+        t.hhi[l] = 0;
+        t.full[l] = 0;
+    }
     for(int c = 0; c < kChecks; c++)
     {
-        t.hlo[c] = 0;
-        t.hhi[c] = 0;
-        t.full[c] = kCheckBits[c][kMaxCheckDegree - 1] >= 0 ? 1 : 0;
+        const int cl = kLaneOfCheck[c];
+        t.full[cl] = kCheckBits[c][kMaxCheckDegree - 1] >= 0 ? 1 : 0;
         for(int j = 0; j < kMaxCheckDegree; j++)
         {
             const int n = kCheckBits[c][j];
             if(n < 0) continue;
-            t.check[n][cnt[n]] = static_cast<int8_t>(c);
-            t.slot[n][cnt[n]] = static_cast<int8_t>(j);
+            e_check[n][cnt[n]] = static_cast<int8_t>(c);  // edges of a bit in ascending check order = the reference's k
+            e_slot[n][cnt[n]] = static_cast<int8_t>(j);
             cnt[n]++;
-            if(n < 64) t.hlo[c] |= (1ull << n);
-            else t.hhi[c] |= (1ull << (n - 64));
+            const int p = t.pos_of_bit[n];
+            if(p < 64) t.hlo[cl] |= (1ull << p);
+            else t.hhi[cl] |= (1ull << (p - 64));
         }
     }
+    for(int h = 0; h < 2; h++)
+        for(int l = 0; l < 64; l++)
+        {
+            const int n = kBitOfLane[h][l];
+            for(int i = 0; i < kEdgesPerBit; i++)
+            {
+                // instructions 0 and 1 may take the bit's first two edges in either order: (tov0 + tov1) + tov2 is commutative in them
+                const int k = (i < 2 && kSwapFirstEdges[n]) ? 1 - i : i;
+                t.cell[h][l][i] = static_cast<uint16_t>(e_slot[n][k] * kTileRowStride + kLaneOfCheck[e_check[n][k]]);
+            }
+        }
     return t;
 }
 
@@ -166,11 +190,12 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 #pragma unroll
     for(int h = 0; h < 2; h++)
 #pragma unroll
-        for(int k = 0; k < kEdgesPerBit; k++) e_addr[h][k] = kEdges.slot[lane + 64 * h][k] * kTStride + kEdges.check[lane + 64 * h][k];
-    const int my_check = lane < kChecks ? lane : 0;
-    const uint64_t hlo = kEdges.hlo[my_check];
-    const uint64_t hhi = kEdges.hhi[my_check];
-    const bool my_full = kEdges.full[my_check] != 0;
+        for(int k = 0; k < kEdgesPerBit; k++) e_addr[h][k] = kEdges.cell[h][lane][k];
+    const uint64_t hlo = kEdges.hlo[lane];  // zero for lanes >= 38
+    const uint64_t hhi = kEdges.hhi[lane];
+    const bool my_full = kEdges.full[lane] != 0;
+    const int bit_of[2] = {kBitOfLane[0][lane], kBitOfLane[1][lane]};
+    const int src_lo = kEdges.pos_of_bit[lane], src_hi = kEdges.pos_of_bit[lane + 64];  // ballot positions of codeword bits lane, lane + 64
 
     // slot 10 of the degree-10 checks is never written: it stays 1.0 so that full-column products ignore it
     for(int t = lane; t < kMaxCheckDegree * kTStride; t += 64) T[t] = 1.0f;
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     {
         const int item = idx[i];
         const float* __restrict__ L = st.llr + (static_cast<size_t>(blockIdx.y) * st.K + item) * kCodeBits;
-        const float llr[2] = {L[lane], L[lane + 64]};
+        const float llr[2] = {L[bit_of[0]], L[bit_of[1]]};
         const float llr_s[2] = {llr[0] * kLog2e, llr[1] * kLog2e};  // log2-scaled copy used by the message passing
         float tov[2][kEdgesPerBit] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
 
@@ -210,9 +235,14 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                 const bool bad0 = cw[0] ? !(llr[0] > 0.0f) : !(llr[0] <= 0.0f);
                 const bool bad1 = cw[1] ? !(llr[1] > 0.0f) : !(llr[1] <= 0.0f);
                 const int nhard = __popcll(__ballot(bad0)) + __popcll(__ballot(bad1));
+                // back to the codeword's own bit order: lane n fetches bits n and n + 64 from the layout-ordered ballots
+                const uint64_t w_lo = (src_lo & 64) ? hi : lo;
+                const uint64_t w_hi = (src_hi & 64) ? hi : lo;
+                const uint64_t c_lo = __ballot(((w_lo >> (src_lo & 63)) & 1ull) != 0);
+                const uint64_t c_hi = __ballot(((w_hi >> (src_hi & 63)) & 1ull) != 0);
                 // codeword MSB first: cw[0] -> bit 63 of m0, cw[64] -> bit 63 of m1
-                const uint64_t m0 = __brevll(lo);
-                const uint64_t m1 = __brevll(hi);
+                const uint64_t m0 = __brevll(c_lo);
+                const uint64_t m1 = __brevll(c_hi);
                 const uint32_t crc_rx = static_cast<uint32_t>((m1 >> 38) & 0x1FFFull);        // cw[77..89]
                 const uint32_t tail = static_cast<uint32_t>((m1 & 0xFFF8000000000000ull) >> 32);  // cw[64..76]
                 const uint32_t crc = crc13_96(m0, tail);

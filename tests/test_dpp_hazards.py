@@ -96,4 +96,4 @@ def test_no_dpp_hazard_in_compiled_kernels(src, extra):
     checked, bad = check_listing(_listing(src, extra))
     assert not bad, bad[:5]
     if src in ("scan.hip", "softbits.hip"):
-        assert checked > 20          # the kernels that carry the hand-written DPP reductions really were inspected
+        assert checked >= 16         # the kernels that carry the hand-written DPP reductions really were inspected
