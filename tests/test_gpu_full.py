@@ -179,3 +179,34 @@ def test_blocked_staging_equals_retained(hip):
             assert e.value.code == -6
             d.decode(hip.STAGE_SCAN)        # stages outside the block loop stay individually runnable
     assert len(want) > 100
+
+
+def test_maximum_grid_single_channel(orc, hip, parity_report):
+    """Largest search grid the option surface allows in practice: width 500 at a quarter-Hz step, all 8 patterns (F = 2001,
+    128 064 candidates per window, threshold 4) - every stage against the oracle on one window with two pings."""
+    cfg = dict(center=1500.0, width=500.0, step=0.25, depth=8, nbadsync_threshold=4)
+    rng = np.random.default_rng(4242)
+    m1, m2 = synth.random_message(rng), synth.random_message(rng)
+    x = synth.synth_audio(5184, [synth.Ping(m1, 300, 4, 1500.0 - 201.3, 3.0, 0.4), synth.Ping(m2, 3000, 2, 1500.0 + 77.77, 6.0, 2.0)], 1000.0, rng)
+    o = orc.Oracle(threads=16, **cfg)
+    cd = o.frontend_audio(x, 2)
+    items_o, idx_o = o.decode_window(cd)
+    with hip.HipDecoder(channels=1, **cfg) as d:
+        assert (d.F, d.D, d.K) == (2001, 8, 128064)
+        d.submit_audio(x)
+        d.decode()
+        items_g = d.dump_candidates(0)
+        idx_g = d.dump_indexes(0)
+        res = d.results()
+    assert np.array_equal(items_o["f0"].view(np.uint32), items_g["f0"].view(np.uint32))
+    rep = parity.compare_scan(o, cd, items_o, items_g)
+    assert rep["near_ties"] <= 128, rep
+    sb = parity.compare_softbits(o, cd, items_o, items_g)
+    assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= 4)[0])
+    same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
+    ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
+    assert ld["marginal_flips"] <= 4, ld
+    assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
+    assert {bytes(m1), bytes(m2)} <= parity.decoded_messages(items_g)
+    assert np.array_equal(res["item"], np.nonzero(items_g["is_message_present"])[0])
+    parity_report("maximum_grid_F2001_D8", dict(scan=rep, softbits=sb, ldpc=ld, decodes=int(len(res))))
