@@ -1,9 +1,10 @@
 // ldpc_bp: log-domain belief propagation for the (128,90) code + CRC-13 + hard-error gate.
 //
 // Replaces ldpc_kernel (ldpc_kernel.cuh:9-249).  The reference runs one 128-thread
-// block per gated candidate; here ONE 64-lane wave decodes one codeword (2 bits, 6 edges per lane):
+// block per gated candidate; here ONE 64-lane wave decodes one codeword (2 bits, 6 edges per lane; which bits a lane
+// owns and which lane walks which check: ldpc_layout.h, annealed for LDS bank conflicts):
 //   * hard decisions live in two 64-bit ballot masks (SGPRs); the 38 parity checks are
-//     popcount(cw & H_row) on lanes 0..37, the hard-error count is a popcount of a ballot -
+//     popcount(cw & H_row) on the 38 check lanes, the hard-error count is a popcount of a ballot -
 //     no 11x38 byte scatter, no block reductions, no barriers;
 //   * tanh(-toc/2) is evaluated once per edge (384 per iteration, the reference recomputes 3840) with
 //     a 5-instruction exp2/rcp form (absolute error ~1.5e-7) and parked in a per-wave LDS tile T[slot][check]; lanes 0..37 then

@@ -4,7 +4,7 @@
 // (channel, frequency hypothesis).  The reference evaluates, for each of 5376 positions and each
 // pattern, 42 taps x 2*num_avg folded samples; here the linearity of the correlation is used:
 //
-//   C[n]      = sum_k conj(cdat2[(n+k) mod N]) * cb42[k]          one pass, 5184 x 42 complex MACs
+//   C[n]      = sum_k conj(cdat2[(n+k) mod N]) * cb42[k]          one pass over the window
 //   S(pos,p)  = sum_{m in mask_p} C[(pos+864m) mod N] + C[(pos+864m+336) mod N]
 //   xb        = |S|
 //
@@ -15,11 +15,9 @@
 //
 // Phases (LDS: one 5184+41 complex buffer, 44 KB per workgroup -> 3 workgroups per CU):
 //  1. mix the window into LDS (custom ~25-instruction sincos, mix.h);
-//  2. C[n]: every thread owns 9 consecutive outputs and streams the 50 samples they need through
-//     registers (50 ds_read_b64 for 378 complex MACs; lane stride 9 samples = 18 dwords is conflict-free
-//     for ds_read_b64).  The 42 taps are +-pp[i] with compile-time signs (msk_context.cuh:188-196) so only
-//     the 12 half-sine values sit in SGPRs; the 7 taps that are exactly zero (pp[0]) are skipped.  After a
-//     barrier C overwrites the window in place;
+//  2. C[n] by pulse decomposition (correlate_pulses below): a thread owns nine outputs spaced by six, which share fifteen
+//     half-pulse sums built from the 90 samples it streams - 165 multiply-adds + 77 adds of complex values per thread
+//     instead of one 42-tap sum per output (693).  After a barrier C overwrites the window in place;
 //  3. fold + |S|^2 per pattern; each wave takes 128-position half-slices, pre-reduces the lane's two
 //     positions, then one DPP max + ballot per (half-slice, pattern).  No barrier in this phase (the
 //     reference has 4 per slice).  Lowest position wins exact ties, as the reference's strict-> trees;

@@ -11,7 +11,9 @@
 // h = lane + 64*s (s = 0,1,2) lives in lane `lane`, slot `s`.  Softbit u needs groups u-1 and u
 // (softbits_kernel.cuh:158-177: I bits 12j..12j+11, Q bits 12j-6..12j+5), so its 12-tap sum starts in
 // the lane of group u-1 (taps pp[0..5]), hops one lane with a DPP wave shift and finishes in lane
-// u%64 with taps pp[6..11] - the reference's tap order, and softbit u ends up in lane u%64 of slot u/64.
+// u%64 with taps pp[6..11], and softbit u ends up in lane u%64 of slot u/64.  The tap sums run on the folded
+// complex samples; the carrier rotation, common to the whole frame, is applied to the two sums of a group.
+// Fold reads are ds_read_b128 (conflict-free at the 48-byte lane stride; see the fold section).
 // From there the two 144-term sums (softbits_kernel.cuh:186-194) are one per-lane add over the three slots plus a
 // single cross-lane reduction carrying both sums (sum_reduction.cuh:14-44 replaced by two interleaved DPP chains).
 // The phase rotation uses conj(s)/|s| instead of atan2f + sincosf (same unit vector to ~1 ulp); the
