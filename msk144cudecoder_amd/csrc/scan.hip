@@ -1,6 +1,6 @@
 // sync_scan: sync-word correlation over frequency x time offset x averaging pattern.
 //
-// Replaces scan_kernel (scan_kernel.cuh:27-393).  One workgroup (9 waves) per
+// Replaces scan_kernel (scan_kernel.cuh:27-393).  One workgroup (8 waves) per
 // (channel, frequency hypothesis).  The reference evaluates, for each of 5376 positions and each
 // pattern, 42 taps x 2*num_avg folded samples; here the linearity of the correlation is used:
 //
@@ -15,9 +15,9 @@
 //
 // Phases (LDS: one 5184+41 complex buffer, 44 KB per workgroup -> 3 workgroups per CU):
 //  1. mix the window into LDS (custom ~25-instruction sincos, mix.h);
-//  2. C[n] by pulse decomposition (correlate_pulses below): a thread owns nine outputs spaced by six, which share fifteen
-//     half-pulse sums built from the 90 samples it streams - 165 multiply-adds + 77 adds of complex values per thread
-//     instead of one 42-tap sum per output (693).  After a barrier C overwrites the window in place;
+//  2. C[n] by pulse decomposition (correlate_pulses below): a thread owns eleven outputs spaced by six, which share
+//     seventeen half-pulse sums built from the 102 samples it streams - 187 multiply-adds + 93 adds of complex values per
+//     thread instead of one 42-tap sum per output (847).  After a barrier C overwrites the window in place;
 //  3. fold + |S|^2 per pattern; each wave takes 128-position half-slices, pre-reduces the lane's two
 //     positions, then one DPP max + ballot per (half-slice, pattern).  No barrier in this phase (the
 //     reference has 4 per slice).  Lowest position wins exact ties, as the reference's strict-> trees;
@@ -37,13 +37,18 @@ namespace msk144
 namespace
 {
 
-constexpr int kOutPerThread = 9;
-constexpr int kScanThreads = kWindowSamples / kOutPerThread;  // 576 = 9 waves: one pass, in-place C
+// Workgroup shape: 8 waves.  A CU holds three 8-wave workgroups with this much LDS but only ~1.5 nine-wave ones
+// (tools/ubench/occupancy_probe.hip: 576 threads + 44.5 KB -> 1.47 resident, 512 threads -> 3), so the natural
+// 576 x 9 outputs split of the 5184-sample window is the wrong one: 512 threads, eleven outputs each in the correlation
+// (79 groups of six threads cover the 864 output columns, the last 38 threads idle through that phase).
+constexpr int kOutPerThread = 11;
+constexpr int kScanThreads = 512;
 constexpr int kScanWaves = kScanThreads / 64;
+constexpr int kMixPerThread = (kWindowSamples + kScanThreads - 1) / kScanThreads;  // 11, the last one on 64 threads only
 constexpr int kChunk = 128;                                   // positions per wave work unit
 constexpr int kChunks = kScanPositions / kChunk;              // 42
 constexpr int kWrapPad = kSyncTaps - 1;
-static_assert(kScanThreads % 64 == 0 && kScanThreads * kOutPerThread == kWindowSamples, "one in-place pass");
+static_assert(kScanThreads % 64 == 0 && kScanThreads * kOutPerThread >= kWindowSamples, "one in-place pass");
 
 struct ScanArgs
 {
@@ -70,17 +75,21 @@ __device__ __forceinline__ float2 as_float2(v2f v)
 //     sum_k x[n+k] * cbi[k] = s1 P[n] + s3 P[n+12] + s5 P[n+24] + s7 A[n+36]    =: R
 //     sum_k x[n+k] * cbq[k] = s0 B[n] + s2 P[n+6]  + s4 P[n+18] + s6 P[n+30]    =: Q
 //     C[n] = sum_k conj(x[n+k]) (cbi[k] + i cbq[k]) = (R.x + Q.y, Q.x - R.y)
-// everything C[n] needs lives at offsets n + 6j.  A thread therefore owns nine outputs SPACED BY SIX, n = n0 + 6r: they share
-// the fifteen half-pulse pairs at n0 + 6i, each built from its own six samples, so the 90 samples a thread streams are
-// used exactly once per rail: 165 multiply-adds and 77 adds of complex values per thread instead of 693 + 72 with one
-// 42-tap sum per output (-2.4 k of the kernel's 8.7 k issue cycles per wave).  Same linear form, different association:
-// ~1e-6 relative on xb, as before.  Thread t = 6q + c owns n0 = 54 q + c.
+// everything C[n] needs lives at offsets n + 6j.  A thread therefore owns R = 11 outputs SPACED BY SIX, n = n0 + 6r: they
+// share the R + 6 half-pulse pairs at n0 + 6i, each built from its own six samples, so the 6 (R + 6) samples a thread
+// streams are used exactly once per rail: 11 (R + 6) multiply-adds and ~8.5 R adds of complex values per thread instead
+// of 77 R + 8 R with one 42-tap sum per output.  Same linear form, different association: ~1e-6 relative on xb, as before.
+// Thread t = 6q + c owns n0 = 66 q + c.
 constexpr int kPulseHalf = 6;
-constexpr int kHalfPulses = kOutPerThread + 6;  // 15 half-pulse positions feed 9 outputs
-constexpr int kStream = kHalfPulses * kPulseHalf;  // 90 samples
-constexpr int kOutSpan = kOutPerThread * kPulseHalf;  // 54 consecutive outputs per group of 6 threads
-static_assert(kWindowSamples % kOutSpan == 0 && (kWindowSamples / kOutSpan) * kPulseHalf == kScanThreads, "thread -> (block of 54, residue) map");
-static_assert(kOutSpan * (kWindowSamples / kOutSpan - 1) + kPulseHalf - 1 + kStream - 1 < kWindowSamples + kWrapPad, "the last thread's stream stays inside the wrap pad");
+constexpr int kHalfPulses = kOutPerThread + 6;  // 17 half-pulse positions feed 11 outputs
+constexpr int kStream = kHalfPulses * kPulseHalf;  // 102 samples
+constexpr int kOutSpan = kOutPerThread * kPulseHalf;  // 66 consecutive outputs per group of 6 threads
+constexpr int kOutColumns = kWindowSamples / kPulseHalf;  // 864 columns n = 6k + c
+constexpr int kOutGroups = (kOutColumns + kOutPerThread - 1) / kOutPerThread;  // 79 groups of six threads
+static_assert(kWindowSamples % kPulseHalf == 0 && kOutGroups * kPulseHalf <= kScanThreads, "thread -> (block of 66, residue) map");
+// the last group's stream runs past the wrap pad: those samples only feed outputs beyond the window, which are dropped
+constexpr int kStreamPad = kOutSpan * (kOutGroups - 1) + kPulseHalf - 1 + kStream - (kWindowSamples + kWrapPad);
+static_assert(kStreamPad > 0 && kStreamPad < 64, "LDS buffer carries kStreamPad readable (unused) samples behind the wrap pad");
 
 template<int kSign>
 __device__ __forceinline__ void acc_signed(float2& acc, const float2 v)
@@ -156,7 +165,7 @@ __device__ __forceinline__ void correlate_pulses(lds_f2_ptr xs, const float (&pp
 template<int kD>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 {
-    __shared__ float2 s_buf[kWindowSamples + kWrapPad + 7];  // mixed window, later C[n] in place
+    __shared__ float2 s_buf[kWindowSamples + kWrapPad + kStreamPad];  // mixed window, later C[n] in place
     __shared__ float s_wv[kScanDepthMax][kChunks];           // per (pattern, half-slice) max |S|^2
     __shared__ uint32_t s_wpos[kScanDepthMax][kChunks];
 
@@ -175,29 +184,37 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     // ---- 1. mix down by the hypothesis frequency (scan_kernel.cuh:45-69) ----
     const float f0 = -1.0f * a.st.freq[b];
     const float2* __restrict__ cdat = a.st.analytic + static_cast<size_t>(ch) * kWindowSamples;
-    float2 xin[kOutPerThread];  // all nine loads in flight before any arithmetic: one L2 latency per tile, not three
+    float2 xin[kMixPerThread];  // all loads in flight before any arithmetic: one L2 latency per tile, not three
 #pragma unroll
-    for(int i = 0; i < kOutPerThread; i++) xin[i] = cdat[tid + i * kScanThreads];
+    for(int i = 0; i < kMixPerThread; i++)
+        if((i + 1) * kScanThreads <= kWindowSamples || tid + i * kScanThreads < kWindowSamples) xin[i] = cdat[tid + i * kScanThreads];
     const float tid_f = static_cast<float>(tid);
 #pragma unroll
-    for(int i = 0; i < kOutPerThread; i++)
+    for(int i = 0; i < kMixPerThread; i++)
     {
         const int n = tid + i * kScanThreads;
-        const float2 y = mix_sample(xin[i], tid_f + static_cast<float>(i * kScanThreads), f0);
-        s_buf[n] = y;
-        if(n < kWrapPad) s_buf[kWindowSamples + n] = y;
+        if((i + 1) * kScanThreads <= kWindowSamples || n < kWindowSamples)
+        {
+            const float2 y = mix_sample(xin[i], tid_f + static_cast<float>(i * kScanThreads), f0);
+            s_buf[n] = y;
+            if(n < kWrapPad) s_buf[kWindowSamples + n] = y;
+        }
     }
     __syncthreads();
 
-    // ---- 2. C[n0 + 6r], r = 0..8, by pulse decomposition (correlate_pulses); C then overwrites the window in place ----
+    // ---- 2. C[n0 + 6r], r = 0..10, by pulse decomposition (correlate_pulses); C then overwrites the window in place ----
     {
         const int q = tid / kPulseHalf;
         const int n0 = kOutSpan * q + (tid - q * kPulseHalf);
         float2 c[kOutPerThread];
-        correlate_pulses((lds_f2_ptr)(s_buf + n0), a.pp, c);
+        if(q < kOutGroups) correlate_pulses((lds_f2_ptr)(s_buf + n0), a.pp, c);
         __syncthreads();  // every thread has read its samples: C may overwrite the window
+        if(q < kOutGroups)
+        {
 #pragma unroll
-        for(int r = 0; r < kOutPerThread; r++) s_buf[n0 + kPulseHalf * r] = c[r];
+            for(int r = 0; r < kOutPerThread; r++)
+                if(n0 + kPulseHalf * r < kWindowSamples) s_buf[n0 + kPulseHalf * r] = c[r];
+        }
     }
     __syncthreads();
 

@@ -217,7 +217,7 @@ int main(int argc, char* const argv[])
               << "Softbit-kernel CUDA threads: " << 160 << std::endl
               << std::endl;
     std::cerr << "msk144hipdecoder: " << F << " frequency hypotheses x " << D << " patterns x 8 = " << F * D * 8 << " candidates per window; HIP workgroups per window: scan "
-              << F << " x 576, softbits " << F << " x 512, LDPC one wave per gated candidate" << std::endl;
+              << F << " x 512, softbits " << F << " x 512, LDPC one wave per gated candidate" << std::endl;
     if(nch > 1) std::cerr << "msk144hipdecoder: " << nch << " input streams per GPU batch, hop timeout " << hop_timeout_ms << " ms" << std::endl;
 
     const size_t sample_bytes = (opt.read_mode == 1) ? sizeof(int16_t) : 2 * sizeof(int8_t);
