@@ -232,9 +232,8 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
                 pi = fmaf(-acc[0][t].x, cbi, pi);
             }
         }
-        row_sum2_f32(pr, pi);
-        const float sre = f32_add(f32_add(readlane_f32(pr, 0), readlane_f32(pr, 16)), f32_add(readlane_f32(pr, 32), readlane_f32(pr, 48)));
-        const float sim = f32_add(f32_add(readlane_f32(pi, 0), readlane_f32(pi, 16)), f32_add(readlane_f32(pi, 32), readlane_f32(pi, 48)));
+        wave_sum2_f32(pr, pi);
+        const float sre = pr, sim = pi;
         // cfac = conj(exp(i*atan2(im,re))) = (re, -im)/|s|
         float cr = 1.0f, ci = 0.0f;
         {
@@ -302,9 +301,9 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         {
             float t = f32_add(f32_add(soft[0], soft[1]), soft[2]);
             float q = fmaf(soft[2], soft[2], fmaf(soft[1], soft[1], f32_mul(soft[0], soft[0])));
-            row_sum2_f32(t, q);
-            sum_sav = f32_add(f32_add(readlane_f32(t, 0), readlane_f32(t, 16)), f32_add(readlane_f32(t, 32), readlane_f32(t, 48)));
-            sum_s2av = f32_add(f32_add(readlane_f32(q, 0), readlane_f32(q, 16)), f32_add(readlane_f32(q, 32), readlane_f32(q, 48)));
+            wave_sum2_f32(t, q);
+            sum_sav = t;
+            sum_s2av = q;
         }
         const float sav = div_by_const<144>(sum_sav);    // correctly rounded, like the reference's division
         const float s2av = div_by_const<144>(sum_s2av);

@@ -158,6 +158,38 @@ __device__ __forceinline__ float readlane_f32(float v, int lane)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// Whole-wave sums of two independent values, (row0 + row1) + (row2 + row3) with the rows summed as in row_sum2_f32: after
+// the four in-row steps, row_bcast:15 adds a row's total into the next row (rows 1 and 3 enabled), row_bcast:31 adds row 1's
+// pair into row 3, and one readlane of lane 63 per value makes the result wave-uniform: 2 DPP + 1 readlane per value where
+// reading the four row totals back costs 4 readlanes + 5 VALU (one SGPR operand per instruction).
+__device__ __forceinline__ void wave_sum2_f32(float& a, float& b)
+{
+    float ra, rb;
+    asm volatile("s_nop 4\n\t"
+                 "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "=&v"(ra), "=&v"(rb)
+                 : "v"(a), "v"(b));
+    a = readlane_f32(ra, 63);
+    b = readlane_f32(rb, 63);
+}
+
 // Sum of a 32-lane half of the wave with the reference's shuffle order (1,2,4,8,16); the result
 // is valid in lanes 0 and 32.  Keeping this order makes 144-term block sums bit-compatible with
 // sum_reduction_two_cycles on 32-lane warps.
