@@ -96,11 +96,35 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     }
     __syncthreads();
 
-    // sync template for the phase estimate: the first sync word covers samples 0..41 = groups 0..6
-    // (lanes 0..6 of slot 0), the second samples 336..377 = groups 56..62 (lanes 56..62 of slot 0).
-    // The 6 taps of a lane are re-read from the (L1-resident) device table for every candidate rather than
-    // kept in 12 registers: that keeps the kernel under 80 VGPRs, i.e. 3 workgroups per CU.
+    // Phase estimate = sum over the two sync words of folded sample x conj(template) (softbits_kernel.cuh:88-137).  The first
+    // sync word covers samples 0..41 = groups 0..6 (lanes 0..6 of slot 0), the second samples 336..377 = groups 56..62.
+    // Inside a group the template is one half of the half-sine pulse on each rail, signed by a sync bit
+    // (msk_context.cuh:188-196: I carries bits 1,1,3,3,5,5,7 and Q bits 0,2,2,4,4,6,6 over the seven groups; even groups
+    // have the rising half on I and the falling half on Q, odd groups the other way round) - so a lane's share of the sum
+    // is a signed combination of the two matched-filter sums u1 = sum x[t] pp[t], u2 = sum x[t] pp[6+t] of its group, which
+    // the demodulator needs anyway:   even: (sI u1.x + sQ u2.y,  sI u1.y - sQ u2.x)    odd: (sI u2.x + sQ u1.y,  sI u2.y - sQ u1.x)
+    // Four per-lane coefficients (0 outside the sync groups) replace the 36 multiply-adds and six table loads per candidate.
     const int cb_group = (lane < 7) ? lane : (lane >= 56 && lane < 63) ? lane - 56 : -1;
+    float k_u1x = 0.0f, k_u2x = 0.0f, k_u1y = 0.0f, k_u2y = 0.0f;  // pr = k_u1x u1.x + k_u2x u2.x + k_u1y u1.y + k_u2y u2.y
+#pragma unroll
+    for(int g = 0; g < 7; g++)
+    {
+        if(cb_group == g)
+        {
+            const float s_i = static_cast<float>(kSync8Pm[2 * (g / 2) + 1]);
+            const float s_q = static_cast<float>(kSync8Pm[2 * ((g + 1) / 2)]);
+            if(g % 2 == 0)
+            {
+                k_u1x = s_i;
+                k_u2y = s_q;
+            }
+            else
+            {
+                k_u2x = s_i;
+                k_u1y = s_q;
+            }
+        }
+    }
     const bool odd = (lane & 1) != 0;
     float pp[12];
 #pragma unroll
@@ -214,24 +238,30 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             }
         }
 
-        // ---- carrier phase from the two sync words (softbits_kernel.cuh:88-137): sum c3[k]*conj(cb[k]) ----
-        float pr = 0.0f, pi = 0.0f;
-        {
-            int g = cb_group < 0 ? 0 : cb_group;
-            asm volatile("" : "+v"(g));  // opaque per iteration: stops the compiler from hoisting the loads (and 12 VGPRs) out of the loop
-            const float2* __restrict__ cbp = a.st.cb42 + g * kGroup;
-            const float keep = cb_group < 0 ? 0.0f : 1.0f;
+        // ---- matched filter on the folded complex samples (softbits_kernel.cuh:157-180 before the rotation of :146-153) ----
+        // The rotation is the same for every sample of the frame, so it commutes with the tap sums: filter the folded complex
+        // samples first (two real FMAs per sample and pulse half) and rotate the two complex sums of a group afterwards - 28
+        // instead of 36 multiply-adds per group.  Same linear form as rotating every sample first, associated differently
+        // (~1e-7 relative).  The folded samples are dead after this loop.
+        v2f u1[kSlots], u2[kSlots];
 #pragma unroll
-            for(int t = 0; t < kGroup; t++)
+        for(int s = 0; s < kSlots; s++)
+        {
+            u1[s] = acc[s][0] * pp[0];
+            u2[s] = acc[s][0] * pp[kGroup];
+#pragma unroll
+            for(int t = 1; t < kGroup; t++)
             {
-                const float2 cbt = cbp[t];
-                const float cbr = cbt.x * keep, cbi = cbt.y * keep;
-                pr = fmaf(acc[0][t].x, cbr, pr);
-                pr = fmaf(acc[0][t].y, cbi, pr);
-                pi = fmaf(acc[0][t].y, cbr, pi);
-                pi = fmaf(-acc[0][t].x, cbi, pi);
+                u1[s].x = fmaf(acc[s][t].x, pp[t], u1[s].x);
+                u1[s].y = fmaf(acc[s][t].y, pp[t], u1[s].y);
+                u2[s].x = fmaf(acc[s][t].x, pp[kGroup + t], u2[s].x);
+                u2[s].y = fmaf(acc[s][t].y, pp[kGroup + t], u2[s].y);
             }
         }
+
+        // ---- carrier phase from the two sync words (softbits_kernel.cuh:88-137): sum c3[k]*conj(cb[k]) ----
+        float pr = fmaf(k_u2y, u2[0].y, fmaf(k_u1y, u1[0].y, fmaf(k_u2x, u2[0].x, k_u1x * u1[0].x)));
+        float pi = fmaf(-k_u2y, u2[0].x, fmaf(-k_u1y, u1[0].x, fmaf(k_u2x, u2[0].y, k_u1x * u1[0].y)));
         wave_sum2_f32(pr, pi);
         const float sre = pr, sim = pi;
         // cfac = conj(exp(i*atan2(im,re))) = (re, -im)/|s|
@@ -251,34 +281,16 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             }
         }
 
-        // ---- de-rotate (softbits_kernel.cuh:146-153) and matched filter (:157-180) ----
+        // ---- de-rotate the filtered sums (softbits_kernel.cuh:146-153) ----
         // va = plane that STARTS a softbit in this lane (even group -> I bit u+1 -> real part,
         // odd group -> Q bit u+1 -> imaginary part); vb = plane that FINISHES softbit u = this group.
         // re = fr*cr - fi*ci, im = fr*ci + fi*cr: pick the coefficient pair per lane once instead of
         // selecting per sample.
         const float a_r = odd ? ci : cr, a_i = odd ? cr : -ci;   // va = fr*a_r + fi*a_i
         const float b_r = odd ? cr : ci, b_i = odd ? -ci : cr;   // vb = fr*b_r + fi*b_i
-        // The rotation is the same for every sample of the frame, so it commutes with the tap sums: filter the folded complex
-        // samples first (two real FMAs per sample and pulse half) and rotate the two complex sums of a group afterwards - 28
-        // instead of 36 multiply-adds per group.  Same linear form as rotating every sample first (softbits_kernel.cuh:146-177),
-        // associated differently (~1e-7 relative).
         float start[kSlots], soft[kSlots];
-        v2f u2[kSlots];
 #pragma unroll
-        for(int s = 0; s < kSlots; s++)
-        {
-            v2f u1 = acc[s][0] * pp[0];
-            u2[s] = acc[s][0] * pp[kGroup];
-#pragma unroll
-            for(int t = 1; t < kGroup; t++)
-            {
-                u1.x = fmaf(acc[s][t].x, pp[t], u1.x);
-                u1.y = fmaf(acc[s][t].y, pp[t], u1.y);
-                u2[s].x = fmaf(acc[s][t].x, pp[kGroup + t], u2[s].x);
-                u2[s].y = fmaf(acc[s][t].y, pp[kGroup + t], u2[s].y);
-            }
-            start[s] = fmaf(u1.y, a_i, u1.x * a_r);
-        }
+        for(int s = 0; s < kSlots; s++) start[s] = fmaf(u1[s].y, a_i, u1[s].x * a_r);
 #pragma unroll
         for(int s = 0; s < kSlots; s++)
         {
