@@ -259,6 +259,12 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     h->params.max_results = st.max_results;
 
     sync_template(h->tpl.re, h->tpl.im, h->tpl.pp);
+    // the kernels skip the multiplications by pp[0] and pp[6] (softbits.hip, scan.hip): exact only for these values
+    if(h->tpl.pp[0] != 0.0f || h->tpl.pp[kPulseSamples / 2] != 1.0f)
+    {
+        h->error = "half-sine pulse table: pp[0] != 0 or pp[6] != 1";
+        return bail(MSK144_EINVAL);
+    }
 
     if(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
     {

@@ -127,9 +127,9 @@ __device__ __forceinline__ void correlate_pulses(lds_f2_ptr xs, const float (&pp
         float2 x[kPulseHalf];
 #pragma unroll
         for(int d = 0; d < kPulseHalf; d++) x[d] = as_float2(xs[off + i * kPulseHalf + d]);
-        // A_i (pp[0] = sin 0 = 0: five terms) and B_i
+        // A_i (pp[0] = sin 0 = 0: five terms) and B_i (pp[6] = 1: the first term is the sample)
         float2 av = make_float2(x[1].x * pp[1], x[1].y * pp[1]);
-        float2 bv = make_float2(x[0].x * pp[6], x[0].y * pp[6]);
+        float2 bv = x[0];  // pp[6] = sin pi/2 = 1 exactly (checked at create)
 #pragma unroll
         for(int d = 2; d < kPulseHalf; d++)
         {

@@ -34,7 +34,10 @@ constexpr int kSbWaves = kSbThreads / 64;
 constexpr int kGroup = 6;                                  // samples per half-bit group
 constexpr int kGroups = kFrameSamples / kGroup;            // 144
 constexpr int kSlots = (kGroups + 63) / 64;                // 3
-constexpr int kRunPad = kGroup - 1;                        // a 6-sample run may cross the ring end
+// The window is a ring of exactly six frames.  LDS carries one more frame (+ one run of samples) behind it, so a
+// folded frame starting anywhere in the ring is 864 CONTIGUOUS samples: its byte address is a wave-uniform frame base
+// (scalar arithmetic) plus a per-lane constant - no per-lane wrap arithmetic in the fold.  48.4 KB, three workgroups per CU.
+constexpr int kRingPad = kFrameSamples + kGroup - 1;
 
 struct SoftbitsArgs
 {
@@ -56,7 +59,7 @@ __device__ __forceinline__ float dpp_add(float v)
 
 __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float2 s_x[kWindowSamples + kRunPad + 3];
+    __shared__ __attribute__((aligned(16))) float2 s_x[kWindowSamples + kRingPad + 3];
 
     const int xcd = blockIdx.x & 7;
     const int tile = xcd * a.tiles_per_xcd + (blockIdx.x >> 3);
@@ -67,7 +70,15 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // Candidates of this wave: c = wave + 8 i, i < D.  Their scan positions are fetched once, lane i holding candidate i's
+    // (the latency hides under the mix phase), and handed out by readlane: the position is a scalar in the candidate loop.
+    const int D = a.st.D;
+    const int ncand = D * kSlotsPerPattern;
+    const size_t item0 = static_cast<size_t>(ch) * a.st.K + static_cast<size_t>(b) * ncand;
+    uint32_t pos_of_lane = 0u;
+    if(lane < D) pos_of_lane = a.st.pos[item0 + wave + kSbWaves * lane];
 
     // ---- mix (softbits_kernel.cuh:27-52) ----
     const float f0 = -1.0f * a.st.freq[b];
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             {
                 const float2 y = mix_sample(xin[i], tid_f + static_cast<float>(i * kSbThreads), f0);
                 s_x[n] = y;
-                if(n < kRunPad) s_x[kWindowSamples + n] = y;
+                if(n < kRingPad) s_x[kWindowSamples + n] = y;
             }
         }
     }
@@ -130,31 +141,34 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
 #pragma unroll
     for(int i = 0; i < 12; i++) pp[i] = a.tpl.pp[i];
 
-    const int D = a.st.D;
-    const int ncand = D * kSlotsPerPattern;
-    const size_t item0 = static_cast<size_t>(ch) * a.st.K + static_cast<size_t>(b) * ncand;
-    constexpr uint32_t kN8 = kWindowSamples * 8u;
     const char* __restrict__ xbytes = reinterpret_cast<const char*>(s_x);
 
-    for(int c = wave; c < ncand; c += kSbWaves)
+    // byte offset of this lane's group inside a frame, per slot.  Slot 2 only has groups 128..143: lanes >= 16 re-read
+    // group 143 (harmless, their results are discarded) so the loop stays convergent.
+    uint32_t lane8[kSlots];
+#pragma unroll
+    for(int s = 0; s < kSlots; s++)
     {
+        const int last = kGroups - 64 * s - 1;
+        const int l = lane < last ? lane : last;
+        lane8[s] = static_cast<uint32_t>(kGroup * (l + 64 * s)) * 8u;
+    }
+    // sync bit this lane checks (softbits 0..7 and 56..63), as +-1; 0 = none
+    int sync_pm = 0;
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+        if(lane == k || lane == kSecondSyncBit + k) sync_pm = kSync8Pm[k];
+
+    for(int i = 0; i < D; i++)
+    {
+        const int c = wave + kSbWaves * i;
         const int p = c / kSlotsPerPattern;
         const size_t item = item0 + c;
-        uint32_t pos = a.st.pos[item];
+        uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), i));
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
 
         // ---- fold the averaged frames (softbits_kernel.cuh:59-82) ----
         v2f acc[kSlots][kGroup];  // (re, im) pairs
-        // byte offset of this lane's group in each slot, frame 0.  Slot 2 only has groups 128..143: lanes
-        // >= 16 re-read group 143 (harmless, their results are discarded) so the loop stays convergent.
-        uint32_t slot8[kSlots];
-#pragma unroll
-        for(int s = 0; s < kSlots; s++)
-        {
-            const int last = kGroups - 64 * s - 1;
-            const int l = lane < last ? lane : last;
-            slot8[s] = (pos + static_cast<uint32_t>(kGroup) * (l + 64 * s)) * 8u;
-        }
         // A lane reads its group's six samples (48 B).  With ds_read_b64 the 48-byte lane stride makes lanes l and l + 16 of a
         // 32-lane access group share a bank pair (6*16 = 0 mod 32): a 2-way conflict on every read, 4 LDS cycles per sample
         // pair and the largest single cost of this kernel.  ds_read_b128 services 16 lanes per cycle, and at this stride their
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
 #pragma unroll
             for(int s = 0; s < kSlots; s++)
             {
-                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + min(slot8[s], slot8[s] - kN8));
+                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + (lane8[s] + pos * 8u));
                 const v4f q0 = q[0], q1 = q[1], q2 = q[2];
                 acc[s][0] = v2f{q0.x, q0.y};
                 acc[s][1] = v2f{q0.z, q0.w};
@@ -183,12 +197,12 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             for(int m = 1; m < kPatternBits; m++)
             {
                 if(!kPatternMask[p][m]) continue;  // wave-uniform
+                uint32_t fb = pos + static_cast<uint32_t>(kFrameSamples * m);  // frame base in the ring: scalar
+                if(fb >= static_cast<uint32_t>(kWindowSamples)) fb -= kWindowSamples;
 #pragma unroll
                 for(int s = 0; s < kSlots; s++)
                 {
-                    const uint32_t a8 = slot8[s] + static_cast<uint32_t>(kFrameSamples * m * 8);  // < 2 * ring
-                    const uint32_t i8 = min(a8, a8 - kN8);
-                    lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8);
+                    lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + (lane8[s] + fb * 8u));
                     const v4f q0 = q[0], q1 = q[1], q2 = q[2];
                     acc[s][0] += v2f{q0.x, q0.y};
                     acc[s][1] += v2f{q0.z, q0.w};
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
 #pragma unroll
             for(int s = 0; s < kSlots; s++)
             {
-                const uint32_t i8 = min(slot8[s], slot8[s] - kN8);
+                const uint32_t i8 = lane8[s] + pos * 8u;
                 lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
                 lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
                 acc[s][0] = r[0];
@@ -218,11 +232,12 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             for(int m = 1; m < kPatternBits; m++)
             {
                 if(!kPatternMask[p][m]) continue;  // wave-uniform
+                uint32_t fb = pos + static_cast<uint32_t>(kFrameSamples * m);
+                if(fb >= static_cast<uint32_t>(kWindowSamples)) fb -= kWindowSamples;
 #pragma unroll
                 for(int s = 0; s < kSlots; s++)
                 {
-                    const uint32_t a8 = slot8[s] + static_cast<uint32_t>(kFrameSamples * m * 8);  // < 2 * ring
-                    const uint32_t i8 = min(a8, a8 - kN8);
+                    const uint32_t i8 = lane8[s] + fb * 8u;
                     lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
                     lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
                     const v2f x0 = r[0];
@@ -247,13 +262,17 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
 #pragma unroll
         for(int s = 0; s < kSlots; s++)
         {
-            u1[s] = acc[s][0] * pp[0];
-            u2[s] = acc[s][0] * pp[kGroup];
+            // pp[0] = sin 0 = 0 and pp[6] = sin pi/2 = 1 exactly (checked at create): the first tap of u1 vanishes, u2's is the sample
+            u1[s] = acc[s][1] * pp[1];
+            u2[s] = acc[s][0];
 #pragma unroll
             for(int t = 1; t < kGroup; t++)
             {
-                u1[s].x = fmaf(acc[s][t].x, pp[t], u1[s].x);
-                u1[s].y = fmaf(acc[s][t].y, pp[t], u1[s].y);
+                if(t > 1)
+                {
+                    u1[s].x = fmaf(acc[s][t].x, pp[t], u1[s].x);
+                    u1[s].y = fmaf(acc[s][t].y, pp[t], u1[s].y);
+                }
                 u2[s].x = fmaf(acc[s][t].x, pp[kGroup + t], u2[s].x);
                 u2[s].y = fmaf(acc[s][t].y, pp[kGroup + t], u2[s].y);
             }
@@ -333,15 +352,8 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         }
 
         // ---- sync-word disagreements (softbits_kernel.cuh:214-241): bits 0..7 and 56..63 ----
-        int sync_bit = -1;
-        if(lane < 8) sync_bit = lane;
-        else if(lane >= kSecondSyncBit) sync_bit = lane - kSecondSyncBit;
-        bool disagree = false;
-        if(sync_bit >= 0)
-        {
-            const int hard = (soft[0] < 0.0f) ? -1 : 1;
-            disagree = hard != kSync8Pm[sync_bit];
-        }
+        const int hard = (soft[0] < 0.0f) ? -1 : 1;
+        const bool disagree = sync_pm != 0 && hard != sync_pm;
         const int nbad = __popcll(__ballot(disagree));
 
         // ---- store (softbits_kernel.cuh:204-211,244-247) ----
