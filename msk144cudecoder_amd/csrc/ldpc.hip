@@ -122,11 +122,14 @@ __device__ __forceinline__ float two_platanh_scaled_full(float x)
 // Same function, priced for what BP actually feeds it: a leave-one-out product of 9-10 tanh values exceeds
 // the 0.9217 breakpoint on ~0.1 % of the edges of a noise codeword (~6 % of the 64-lane edge instructions have
 // such a lane), so the two lower pieces (one max, no selects) run unconditionally and the three upper pieces
-// sit behind a wave-uniform branch.  Bit-identical to two_platanh_scaled_full for every input.
+// sit behind a wave-uniform branch.
 __device__ __forceinline__ float two_platanh_scaled(float x)
 {
     const float z = __builtin_fabsf(x);
-    float v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), (z - 0.4064f) * (kLog2e * 2.0f / 0.322f));
+    // second piece as one fma, z r - c r: the rounded constant c r moves it by <= 1.6 ulp against (z - c) r - the same
+    // order as multiplying by the rounded reciprocal instead of dividing - and saves an instruction on every edge
+    constexpr float kR2 = kLog2e * 2.0f / 0.322f;
+    float v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), __builtin_fmaf(z, kR2, -0.4064f * kR2));
     if(__builtin_expect(__builtin_amdgcn_ballot_w64(z > 0.9217f) != 0ull, 0))
     {
         float c = 0.4064f, r = kLog2e * 2.0f / 0.322f;
@@ -140,7 +143,8 @@ __device__ __forceinline__ float two_platanh_scaled(float x)
             c = 0.9914f;
             r = kLog2e * 2.0f / 0.0012f;
         }
-        v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), (z - c) * r);
+        const float second = (z > 0.9217f) ? (z - c) * r : __builtin_fmaf(z, kR2, -0.4064f * kR2);  // lanes below the breakpoint keep the fast form
+        v = __builtin_fmaxf(z * (kLog2e * 2.0f / 0.83f), second);
         if(z > 0.9998f) v = kLog2e * 14.0f;
     }
     return __builtin_copysignf(v, x);
@@ -195,8 +199,12 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     const uint64_t hlo = kEdges.hlo[lane];  // zero for lanes >= 38
     const uint64_t hhi = kEdges.hhi[lane];
     const bool my_full = kEdges.full[lane] != 0;
+    const uint64_t full_mask = __ballot(my_full && lane < kChecks);
     const int bit_of[2] = {kBitOfLane[0][lane], kBitOfLane[1][lane]};
     const int src_lo = kEdges.pos_of_bit[lane], src_hi = kEdges.pos_of_bit[lane + 64];  // ballot positions of codeword bits lane, lane + 64
+
+    // LDS byte address of this wave's tile, for the M0-relative column stores
+    const uint32_t tile_m0 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) float*)T)));
 
     // slot 10 of the degree-10 checks is never written: it stays 1.0 so that full-column products ignore it
     for(int t = lane; t < kMaxCheckDegree * kTStride; t += 64) T[t] = 1.0f;
@@ -279,19 +287,61 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             if(lane < kChecks)
             {
                 float t[kMaxCheckDegree];
-#pragma unroll
-                for(int j = 0; j < kMaxCheckDegree; j++) t[j] = T[j * kTStride + lane];
+                asm volatile("s_mov_b32 m0, %11\n\t"
+                             "s_nop 0\n\t"
+                             "ds_read_addtid_b32 %0 offset:%c12\n\t"
+                             "ds_read_addtid_b32 %1 offset:%c13\n\t"
+                             "ds_read_addtid_b32 %2 offset:%c14\n\t"
+                             "ds_read_addtid_b32 %3 offset:%c15\n\t"
+                             "ds_read_addtid_b32 %4 offset:%c16\n\t"
+                             "ds_read_addtid_b32 %5 offset:%c17\n\t"
+                             "ds_read_addtid_b32 %6 offset:%c18\n\t"
+                             "ds_read_addtid_b32 %7 offset:%c19\n\t"
+                             "ds_read_addtid_b32 %8 offset:%c20\n\t"
+                             "ds_read_addtid_b32 %9 offset:%c21\n\t"
+                             "ds_read_addtid_b32 %10 offset:%c22\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10])
+                             : "s"(tile_m0), "n"(0 * kTStride * 4), "n"(1 * kTStride * 4), "n"(2 * kTStride * 4), "n"(3 * kTStride * 4), "n"(4 * kTStride * 4), "n"(5 * kTStride * 4),
+                               "n"(6 * kTStride * 4), "n"(7 * kTStride * 4), "n"(8 * kTStride * 4), "n"(9 * kTStride * 4), "n"(10 * kTStride * 4)
+                             : "memory");
                 float pre[kMaxCheckDegree];  // pre[j] = t0*...*t(j-1)
                 pre[0] = 1.0f;
 #pragma unroll
                 for(int j = 1; j < kMaxCheckDegree; j++) pre[j] = pre[j - 1] * t[j - 1];
                 float suf = -1.0f;           // -(t(j+1)*...*t10): the column is stored NEGATED, ready for platanh(-product)
+                float out[kMaxCheckDegree];
+                uint64_t exec_save;
 #pragma unroll
                 for(int j = kMaxCheckDegree - 1; j >= 0; j--)
                 {
-                    T[j * kTStride + lane] = pre[j] * suf;
+                    out[j] = pre[j] * suf;
                     suf *= t[j];
                 }
+                // The column store is base + 4 j stride + 4 lane: ds_write_addtid_b32 takes that address from M0 + offset + 4*lane
+                // and moves no address VGPR to the LDS - 2 cycles per store instead of ds_write_b32's 4 (MI355X_MICROARCH.md, LDS).
+                static_assert(kMaxCheckDegree == 11, "eleven column stores below");
+                asm volatile("s_mov_b32 m0, %12\n\t"
+                             "s_nop 0\n\t"  // SALU write of M0 -> LDS add-TID instruction: one wait state
+                             "ds_write_addtid_b32 %1 offset:%c13\n\t"
+                             "ds_write_addtid_b32 %2 offset:%c14\n\t"
+                             "ds_write_addtid_b32 %3 offset:%c15\n\t"
+                             "ds_write_addtid_b32 %4 offset:%c16\n\t"
+                             "ds_write_addtid_b32 %5 offset:%c17\n\t"
+                             "ds_write_addtid_b32 %6 offset:%c18\n\t"
+                             "ds_write_addtid_b32 %7 offset:%c19\n\t"
+                             "ds_write_addtid_b32 %8 offset:%c20\n\t"
+                             "ds_write_addtid_b32 %9 offset:%c21\n\t"
+                             "ds_write_addtid_b32 %10 offset:%c22\n\t"
+                             "s_mov_b64 %0, exec\n\t"
+                             "s_and_b64 exec, exec, %24\n\t"   // slot 10 exists only in the degree-11 checks; the others keep its constant 1.0
+                             "ds_write_addtid_b32 %11 offset:%c23\n\t"
+                             "s_mov_b64 exec, %0"
+                             : "=&s"(exec_save)
+                             : "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7]), "v"(out[8]), "v"(out[9]), "v"(out[10]),
+                               "s"(tile_m0), "n"(0 * kTStride * 4), "n"(1 * kTStride * 4), "n"(2 * kTStride * 4), "n"(3 * kTStride * 4), "n"(4 * kTStride * 4), "n"(5 * kTStride * 4),
+                               "n"(6 * kTStride * 4), "n"(7 * kTStride * 4), "n"(8 * kTStride * 4), "n"(9 * kTStride * 4), "n"(10 * kTStride * 4), "s"(full_mask)
+                             : "memory");
             }
             __builtin_amdgcn_wave_barrier();
 
@@ -306,9 +356,6 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             for(int h = 0; h < 2; h++)
 #pragma unroll
                 for(int k = 0; k < kEdgesPerBit; k++) tov[h][k] = two_platanh_scaled(prod[h][k]);
-            __builtin_amdgcn_wave_barrier();
-            // restore the constant slot the column pass overwrote
-            if(lane < kChecks && !my_full) T[(kMaxCheckDegree - 1) * kTStride + lane] = 1.0f;
         }
     }
 }

@@ -2,7 +2,9 @@
 
 wave64.h carries hand-counted wait states inside inline-asm strings (hipcc inserts no hazard nops for asm statements):
   * a DPP instruction needs >= 2 wait states after a VALU write of a VGPR it reads;
-  * a DPP instruction needs >= 5 wait states after a VALU write of EXEC (v_cmpx*).
+  * a DPP instruction needs >= 5 wait states after a VALU write of EXEC (v_cmpx*);
+  * an LDS add-TID instruction (ds_write_addtid_b32 / ds_read_addtid_b32, ldpc.hip) needs >= 1 wait state after an SALU write of M0
+    (skipping it sent one column store per wave through a stale M0: a BP iteration count off by one in 1 of 22 000 codewords).
 This test compiles every kernel source with the build's own flags, walks each straight-line stretch of the listing and
 asserts both rules for EVERY *_dpp instruction (the compiler's own included).  One wait state = one instruction issued in
 between; `s_nop N` counts N + 1.  A label or branch ends the look-back (hazards across control flow are the compiler's, and no
@@ -53,6 +55,15 @@ def check_listing(lines):
         if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
             window = []
             continue
+        if "_addtid_" in op:
+            checked += 1
+            states = 0
+            for mn, written, exec_write, provides in reversed(window):
+                if mn == "M0WRITE" and states < 1:
+                    bad.append((ln, raw.strip(), "no wait state after the SALU write of M0, need 1"))
+                states += provides
+                if states >= 1:
+                    break
         if "_dpp" in op:
             checked += 1
             operands = [a.strip() for a in args.split(",")]
@@ -67,6 +78,8 @@ def check_listing(lines):
                 if states >= 5:
                     break
         written, exec_write, provides = set(), False, 1
+        if op.startswith("s_") and args.split(",")[0].strip() == "m0":
+            op = "M0WRITE"
         if op == "s_nop":
             provides = int(args.strip() or "0", 0) + 1
         elif op.startswith("v_"):
@@ -89,6 +102,9 @@ def test_checker_catches_a_planted_hazard():
     n, bad = check_listing(["\tv_cmpx_gt_f32_e32 v1, v2", "\ts_nop 3", "\tv_max_f32_dpp v4, v5, v5 row_mirror row_mask:0xf bank_mask:0xf"])
     assert len(bad) == 1 and "EXEC" in bad[0][2]
     assert check_listing(["\tv_cmpx_gt_f32_e32 v1, v2", "\ts_nop 4", "\tv_max_f32_dpp v4, v5, v5 row_mirror row_mask:0xf bank_mask:0xf"])[1] == []
+    n, bad = check_listing(["\ts_mov_b32 m0, s4", "\tds_write_addtid_b32 v1 offset:0"])
+    assert n == 1 and len(bad) == 1 and "M0" in bad[0][2]
+    assert check_listing(["\ts_mov_b32 m0, s4", "\ts_nop 0", "\tds_write_addtid_b32 v1 offset:0", "\tds_read_addtid_b32 v2 offset:4"]) == (2, [])
 
 
 @pytest.mark.parametrize("src,extra", [(s, e) for s, e in B.SOURCES if s.endswith(".hip")])
@@ -97,3 +113,5 @@ def test_no_dpp_hazard_in_compiled_kernels(src, extra):
     assert not bad, bad[:5]
     if src in ("scan.hip", "softbits.hip"):
         assert checked >= 16         # the kernels that carry the hand-written DPP reductions really were inspected
+    if src == "ldpc.hip":
+        assert checked >= 22         # eleven add-TID column loads and eleven stores
