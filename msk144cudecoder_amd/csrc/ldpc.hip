@@ -187,7 +187,10 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     const int wave = threadIdx.x >> 6;
     const int n_idx = st.n_idx[ch];
     const size_t off = static_cast<size_t>(ch) * st.K;
-    const int32_t* __restrict__ idx = st.idx + off;
+    // the gated-item list is read through the constant address space: uniform addresses become scalar loads (s_load_dword)
+    // that return into SGPRs asynchronously - a VMEM load of a uniform value is followed at once by vmcnt(0) + readfirstlane
+    typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
+    const const_i32_ptr idx = (const_i32_ptr)(st.idx + off);
     float* T = s_t[wave];
 
     // per-lane graph constants: bits lane and lane+64
@@ -209,11 +212,35 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     // slot 10 of the degree-10 checks is never written: it stays 1.0 so that full-column products ignore it
     for(int t = lane; t < kMaxCheckDegree * kTStride; t += 64) T[t] = 1.0f;
 
-    for(int i = blockIdx.x * kLdpcWaves + wave; i < n_idx; i += gridDim.x * kLdpcWaves)
+    // Software pipeline over this wave's codewords: the index entry of codeword n+2 and the two LLRs of codeword n+1 are
+    // fetched while codeword n iterates, so a codeword starts without the two dependent global-memory latencies
+    // (idx -> LLR row) it would otherwise wait out - the kernel is latency-bound (7 waves per SIMD, three LDS round trips
+    // per iteration), not issue-bound.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int stride = static_cast<int>(gridDim.x) * kLdpcWaves;
+    const float* __restrict__ llr_rows = st.llr + static_cast<size_t>(blockIdx.y) * st.K * kCodeBits;
+    int i = static_cast<int>(blockIdx.x) * kLdpcWaves + wave_u;
+    int item_next = i < n_idx ? idx[i] : 0;
+    int item_after = i + stride < n_idx ? idx[i + stride] : 0;
+    float llr_next[2] = {0.0f, 0.0f};
+    if(i < n_idx)
     {
-        const int item = idx[i];
-        const float* __restrict__ L = st.llr + (static_cast<size_t>(blockIdx.y) * st.K + item) * kCodeBits;
-        const float llr[2] = {L[bit_of[0]], L[bit_of[1]]};
+        const float* __restrict__ L = llr_rows + static_cast<size_t>(item_next) * kCodeBits;
+        llr_next[0] = L[bit_of[0]];
+        llr_next[1] = L[bit_of[1]];
+    }
+    for(; i < n_idx; i += stride)
+    {
+        const int item = item_next;
+        const float llr[2] = {llr_next[0], llr_next[1]};
+        item_next = item_after;
+        if(i + stride < n_idx)
+        {
+            const float* __restrict__ L = llr_rows + static_cast<size_t>(item_next) * kCodeBits;
+            llr_next[0] = L[bit_of[0]];
+            llr_next[1] = L[bit_of[1]];
+        }
+        if(i + 2 * stride < n_idx) item_after = idx[i + 2 * stride];
         const float llr_s[2] = {llr[0] * kLog2e, llr[1] * kLog2e};  // log2-scaled copy used by the message passing
         float tov[2][kEdgesPerBit] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
 
