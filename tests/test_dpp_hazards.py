@@ -115,3 +115,22 @@ def test_no_dpp_hazard_in_compiled_kernels(src, extra):
         assert checked >= 16         # the kernels that carry the hand-written DPP reductions really were inspected
     if src == "ldpc.hip":
         assert checked >= 22         # eleven add-TID column loads and eleven stores
+
+
+def test_m0_is_only_touched_inside_our_asm_blocks_of_the_ldpc_kernel():
+    """The add-TID column loads/stores of ldpc.hip set M0 inside their own asm statements and do not list it as a clobber
+    (clang warns that a reserved register on the clobber list may not be preserved): sound as long as the compiler itself
+    never keeps a value in M0 in this kernel - checked here on the listing."""
+    src, extra = next((s, e) for s, e in B.SOURCES if s == "ldpc.hip")
+    inside, ours, foreign = False, 0, []
+    for ln, raw in enumerate(_listing(src, extra), 1):
+        if "#ASMSTART" in raw:
+            inside = True
+        elif "#ASMEND" in raw:
+            inside = False
+        elif re.search(r"\bm0\b", raw.split(";")[0]):
+            if inside:
+                ours += 1
+            else:
+                foreign.append((ln, raw.strip()))
+    assert ours >= 2 and not foreign, foreign[:5]
