@@ -43,11 +43,14 @@ namespace
 // (79 groups of six threads cover the 864 output columns, the last 38 threads idle through that phase).
 constexpr int kOutPerThread = 11;
 constexpr int kScanThreads = 512;
-constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kMixPerThread = (kWindowSamples + kScanThreads - 1) / kScanThreads;  // 11, the last one on 64 threads only
-constexpr int kChunk = 128;                                   // positions per wave work unit
-constexpr int kChunks = kScanPositions / kChunk;              // 42
 constexpr int kWrapPad = kSyncTaps - 1;
+// Fold / arg-max phase: a lane walks a RUN of eleven consecutive positions of one 256-position slice with running maxima
+// (no cross-lane reduction at all); 24 lanes cover a slice (23 x 11 = 253, the 24th run restarts at 245 and overlaps - duplicates
+// cannot change a maximum), 21 x 24 = 504 of the 512 lanes are busy.
+constexpr int kRun = 11;
+constexpr int kRunsPerSlice = (kSlicePositions + kRun - 1) / kRun;  // 24
+static_assert(kScanSlices * kRunsPerSlice <= kScanThreads && kRun <= kWrapPad, "one run per lane; a run may cross the ring end inside the pad");
 static_assert(kScanThreads % 64 == 0 && kScanThreads * kOutPerThread >= kWindowSamples, "one in-place pass");
 
 struct ScanArgs
@@ -166,8 +169,8 @@ template<int kD>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 {
     __shared__ float2 s_buf[kWindowSamples + kWrapPad + kStreamPad];  // mixed window, later C[n] in place
-    __shared__ float s_wv[kScanDepthMax][kChunks];           // per (pattern, half-slice) max |S|^2
-    __shared__ uint32_t s_wpos[kScanDepthMax][kChunks];
+    __shared__ float s_xb[kScanDepthMax][kScanSlices];        // per (pattern, slice): max |S| ...
+    __shared__ uint32_t s_xpos[kScanDepthMax][kScanSlices];   // ... and its position
 
     // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
     // contiguous range of tiles - the F tiles of a channel then share one L2 copy of its window.
@@ -213,130 +216,143 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         {
 #pragma unroll
             for(int r = 0; r < kOutPerThread; r++)
-                if(n0 + kPulseHalf * r < kWindowSamples) s_buf[n0 + kPulseHalf * r] = c[r];
+            {
+                const int n = n0 + kPulseHalf * r;
+                if(n < kWindowSamples) s_buf[n] = c[r];
+                if(n < kRun) s_buf[kWindowSamples + n] = c[r];  // a run of the fold phase may cross the ring end
+            }
         }
     }
     __syncthreads();
 
-    // ---- 3. fold per pattern, |S|^2, arg-max per 128-position half-slice ----
-    // kD is a template parameter: the pattern loop is straight-line code and all 4*frames LDS reads of a
-    // chunk are in flight together.  Patterns 7 and 8 (100100, 100110) reuse the frames already loaded.
+    // ---- 3. fold per pattern, |S|^2, running arg-max along this lane's run of positions ----
+    // kD is a template parameter: the pattern loop is straight-line code.  Patterns 7 and 8 (100100, 100110) reuse the frames
+    // already loaded.  Lane stride = 11 positions = 22 dwords: the 32 lanes of a ds_read_b64 group tile all 64 banks.
     constexpr int D = kD;
     constexpr int kFrames = kD < kPatternBits ? kD : kPatternBits;
-    constexpr uint32_t kN8 = kWindowSamples * 8u;  // byte size of the ring
-    const char* __restrict__ cbytes = reinterpret_cast<const char*>(s_buf);
-    for(int chunk = wave; chunk < kChunks; chunk += kScanWaves)
+    const bool has_run = tid < kScanSlices * kRunsPerSlice;
+    float best[D];
+    uint32_t bidx[D];
+#pragma unroll
+    for(int p = 0; p < D; p++)
     {
-        float2 ca[2][kFrames], cb[2][kFrames];
-        // Ring addresses of the 4*frames samples.  The wrap decision (pos + offset >= 5184) is the same for all 128 positions
-        // of a chunk unless one of the 13 wrap points falls inside it (12 of the 42 chunks): the common case is one scalar
-        // offset per frame/partner and a single v_add per load; the per-lane add/sub/min chain (72 VALU instructions per
-        // chunk) is kept for the chunks that need it.
-        const int chunk_u = __builtin_amdgcn_readfirstlane(chunk);
-        const uint32_t p0 = static_cast<uint32_t>(chunk_u) * kChunk;  // first position of the chunk, 0..5248
-        uint32_t base_a[kFrames], base_b[kFrames];
-        bool uniform = p0 + (kChunk - 1) < static_cast<uint32_t>(kWindowSamples) || p0 >= static_cast<uint32_t>(kWindowSamples);
-        const uint32_t q0 = p0 >= static_cast<uint32_t>(kWindowSamples) ? p0 - kWindowSamples : p0;
+        best[p] = 0.0f;  // |S|^2 = 0 everywhere keeps position 0 of the run: lowest position wins ties
+        bidx[p] = 0u;
+    }
+    if(has_run)
+    {
+        const int slice = tid / kRunsPerSlice;
+        const int k = tid - slice * kRunsPerSlice;
+        const int in_slice = k * kRun < kSlicePositions - kRun ? k * kRun : kSlicePositions - kRun;  // last run: 245..255
+        const uint32_t start = static_cast<uint32_t>(slice * kSlicePositions + in_slice);            // 0..5365
+        typedef const volatile __attribute__((address_space(3))) v2f* lds_run_ptr;
+        lds_run_ptr pa[kFrames], pb[kFrames];
 #pragma unroll
         for(int m = 0; m < kFrames; m++)
         {
-            uint32_t ta = q0 + static_cast<uint32_t>(kFrameSamples * m);
-            if(ta >= static_cast<uint32_t>(kWindowSamples)) ta -= kWindowSamples;
+            uint32_t ta = start + static_cast<uint32_t>(kFrameSamples * m);  // < 2 * ring
+            ta = min(ta, ta - static_cast<uint32_t>(kWindowSamples));
+            ta = min(ta, ta - static_cast<uint32_t>(kWindowSamples));        // start itself may exceed the ring (positions reach 5375)
             uint32_t tb = ta + kSecondSyncSample;
-            if(tb >= static_cast<uint32_t>(kWindowSamples)) tb -= kWindowSamples;
-            uniform = uniform && ta + (kChunk - 1) < static_cast<uint32_t>(kWindowSamples) && tb + (kChunk - 1) < static_cast<uint32_t>(kWindowSamples);
-            base_a[m] = ta * 8u;
-            base_b[m] = tb * 8u;
+            tb = min(tb, tb - static_cast<uint32_t>(kWindowSamples));
+            pa[m] = (lds_run_ptr)(s_buf + ta);
+            pb[m] = (lds_run_ptr)(s_buf + tb);
         }
-        if(uniform)
+#pragma unroll
+        for(int i = 0; i < kRun; i++)
         {
+            float2 ca[kFrames], cb[kFrames];
 #pragma unroll
-            for(int j = 0; j < 2; j++)
+            for(int m = 0; m < kFrames; m++)
             {
-                const uint32_t l8 = static_cast<uint32_t>(j * 64 + lane) * 8u;
-#pragma unroll
-                for(int m = 0; m < kFrames; m++)
-                {
-                    ca[j][m] = *reinterpret_cast<const float2*>(cbytes + (l8 + base_a[m]));
-                    cb[j][m] = *reinterpret_cast<const float2*>(cbytes + (l8 + base_b[m]));
-                }
+                ca[m] = as_float2(pa[m][i]);
+                cb[m] = as_float2(pb[m][i]);
             }
-        }
-        else
-        {
+            float sr = 0.0f, si = 0.0f;
 #pragma unroll
-            for(int j = 0; j < 2; j++)
+            for(int p = 0; p < D; p++)
             {
-                const uint32_t pos = chunk * kChunk + j * 64 + lane;  // 0..5375
-                const uint32_t q8 = (pos >= static_cast<uint32_t>(kWindowSamples) ? pos - kWindowSamples : pos) * 8u;
-#pragma unroll
-                for(int m = 0; m < kFrames; m++)
+                if(p == 0)
                 {
-                    const uint32_t a8 = q8 + static_cast<uint32_t>(kFrameSamples * 8 * m);
-                    const uint32_t ia = min(a8, a8 - kN8);  // a8 mod ring (unsigned wrap trick)
-                    const uint32_t b8 = ia + kSecondSyncSample * 8u;
-                    const uint32_t ib = min(b8, b8 - kN8);
-                    ca[j][m] = *reinterpret_cast<const float2*>(cbytes + ia);
-                    cb[j][m] = *reinterpret_cast<const float2*>(cbytes + ib);
+                    sr = ca[0].x + cb[0].x;
+                    si = ca[0].y + cb[0].y;
                 }
-            }
-        }
-        float sr[2] = {0.0f, 0.0f}, si[2] = {0.0f, 0.0f};
-#pragma unroll
-        for(int p = 0; p < D; p++)
-        {
-            float v[2];
-#pragma unroll
-            for(int j = 0; j < 2; j++)
-            {
-                if(p < kPatternBits)
+                else if(p < kPatternBits)
                 {
-                    sr[j] = (sr[j] + ca[j][p].x) + cb[j][p].x;  // nested prefix masks: add frame p
-                    si[j] = (si[j] + ca[j][p].y) + cb[j][p].y;
+                    sr = (sr + ca[p].x) + cb[p].x;  // nested prefix masks: add frame p
+                    si = (si + ca[p].y) + cb[p].y;
                 }
                 else
                 {
-                    sr[j] = 0.0f;
-                    si[j] = 0.0f;
+                    sr = ca[0].x + cb[0].x;  // patterns 7 and 8 (100100, 100110) start from frame 0 again
+                    si = ca[0].y + cb[0].y;
 #pragma unroll
-                    for(int m = 0; m < kPatternBits; m++)
+                    for(int m = 1; m < kPatternBits; m++)
                     {
                         if(kPatternMask[p][m])
                         {
-                            sr[j] = (sr[j] + ca[j][m].x) + cb[j][m].x;
-                            si[j] = (si[j] + ca[j][m].y) + cb[j][m].y;
+                            sr = (sr + ca[m].x) + cb[m].x;
+                            si = (si + ca[m].y) + cb[m].y;
                         }
                     }
                 }
-                v[j] = fmaf(sr[j], sr[j], si[j] * si[j]);
+                const float v = fmaf(sr, sr, si * si);
+                // strict >: the lowest position keeps exact ties.  Compare into an SGPR pair and select with the VOP3 form: the
+                // VCC form of v_cndmask measures 15-23 cycles per wave-instruction on gfx950 against 4.3
+                // (profiles/r02_valu_issue_microbench.txt); the value itself is a plain max.
+                unsigned long long better;
+                asm("v_cmp_gt_f32_e64 %[m], %[v], %[b]\n\t"
+                    "v_max_f32_e32 %[b], %[v], %[b]\n\t"
+                    "v_cndmask_b32_e64 %[x], %[x], %[i], %[m]"
+                    : [b] "+v"(best[p]), [x] "+v"(bidx[p]), [m] "=&s"(better)
+                    : [v] "v"(v), [i] "n"(i));
             }
-            // lane-local best of its two positions (lower position wins ties), then across the wave
-            const bool second = v[1] > v[0];
-            const float best = second ? v[1] : v[0];
-            const float mx = wave_max_f32(best);
-            // among lanes holding the maximum, the lowest position: first halves (j=0) come before second halves
-            const unsigned long long eq = __ballot(best == mx);
-            const unsigned long long sec = __ballot(second);
-            const unsigned long long eq0 = eq & ~sec;
-            const unsigned long long eq1 = eq & sec;
-            if(lane == 0)
-            {
-                uint32_t off = 0;
-                if(eq0) off = __builtin_ctzll(eq0);
-                else if(eq1) off = 64 + __builtin_ctzll(eq1);
-                s_wv[p][chunk] = mx;
-                s_wpos[p][chunk] = static_cast<uint32_t>(chunk * kChunk) + off;
-            }
+            // every pattern's running maximum of this position is complete before the next position's loads may issue
+            // (patterns 7 and 8 do not depend on all frames, so tying only the last sum would let the others pile up):
+            // the window pointers are volatile, so the next position's loads stay behind this statement; its operands make
+            // the statement wait for this position's arithmetic
+            asm volatile("" : "+v"(best[0]), "+v"(best[D - 1]), "+v"(best[D > 6 ? 5 : 0]), "+v"(best[D > 7 ? 6 : 0]));
+        }
+#pragma unroll
+        for(int p = 0; p < D; p++) bidx[p] += start;
+    }
+    __syncthreads();  // every wave has left the fold loop: nothing needs C any more
+
+    // ---- 3b. the 24 runs of a slice meet through the (now free) window buffer ----
+    {
+        float* run_v = reinterpret_cast<float*>(s_buf);                               // [D][512]
+        uint32_t* run_pos = reinterpret_cast<uint32_t*>(s_buf) + kScanDepthMax * kScanThreads;
+#pragma unroll
+        for(int p = 0; p < D; p++)
+        {
+            run_v[p * kScanThreads + tid] = best[p];
+            run_pos[p * kScanThreads + tid] = bidx[p];
         }
     }
     __syncthreads();
 
-    // ---- 4a. xb = |S| for the 42*D half-slice maxima, in parallel (correctly rounded sqrt) ----
-    for(int e = tid; e < D * kChunks; e += kScanThreads)
+    // ---- 4a. slice maximum = first strict maximum over its runs in position order (the reference's strict-> trees keep the
+    //      lowest position on exact ties; the overlapping last run only repeats positions), xb = |S| (correctly rounded sqrt) ----
+    for(int e = tid; e < D * kScanSlices; e += kScanThreads)
     {
-        const int p = e / kChunks;
-        const int c = e - p * kChunks;
-        s_wv[p][c] = f32_sqrt(s_wv[p][c]);
+        const int p = e / kScanSlices;
+        const int sl = e - p * kScanSlices;
+        const float* rv = reinterpret_cast<const float*>(s_buf) + p * kScanThreads + sl * kRunsPerSlice;
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(s_buf) + (kScanDepthMax + p) * kScanThreads + sl * kRunsPerSlice;
+        float bv = rv[0];
+        uint32_t bp = rp[0];
+        for(int k = 1; k < kRunsPerSlice; k++)
+        {
+            const float v = rv[k];
+            const uint32_t q = rp[k];
+            if(v > bv)
+            {
+                bv = v;
+                bp = q;
+            }
+        }
+        s_xb[p][sl] = f32_sqrt(bv);
+        s_xpos[p][sl] = bp;
     }
     __syncthreads();
 
@@ -350,11 +366,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         uint32_t my_pos = 0u;
         for(int s = 0; s < kScanSlices; s++)
         {
-            // slice maximum = better of its two halves, lower position on ties
-            const float v0 = s_wv[pc][2 * s], v1 = s_wv[pc][2 * s + 1];
-            const bool second = v1 > v0;
-            const float best = second ? v1 : v0;
-            const uint32_t best_pos = second ? s_wpos[pc][2 * s + 1] : s_wpos[pc][2 * s];
+            const float best = s_xb[pc][s];
+            const uint32_t best_pos = s_xpos[pc][s];
             // arg-min over the 8 stored slots of this pattern, lowest slot index wins ties
             const float mn = oct_min_f32(my_xb);
             const unsigned long long eq = __ballot(my_xb == mn);
