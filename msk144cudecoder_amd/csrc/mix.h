@@ -11,10 +11,9 @@ namespace msk144
 // sin and cos of a float angle |phi| < ~1e4 rad, about 1.5 ulp: two-constant Cody-Waite reduction by
 // pi/2 with FMA, cephes minimax polynomials on [-pi/4, pi/4].  Replaces ocml sincosf (~4x the
 // instructions); the reference uses CUDA's sincosf, itself ~2 ulp.
-// Priced with profiles/r02_valu_issue_microbench.txt: the quadrant fix-up avoids v_cndmask with a VCC mask (16-23
-// cycles per wave-instruction on gfx950, against 2.45 for a plain ALU op), v_cmp, v_rndne and v_cvt (4.3 each):
-// k = rint(phi*2/pi) comes from the 1.5*2^23 add trick, whose float bits also hold k mod 4, and the swap / sign
-// flips are bit operations.
+// The quadrant fix-up is pure bit arithmetic (no v_cmp / v_cndmask / v_rndne / v_cvt, all half rate,
+// profiles/r02_valu_issue_microbench.txt): k = rint(phi*2/pi) comes from the 1.5*2^23 add trick, whose float bits also hold
+// k mod 4, and the swap / sign flips are bit operations.
 __device__ __forceinline__ void sincos_reduced(float phi, float& sn, float& cs)
 {
     constexpr float kRound = 12582912.0f;                             // 1.5 * 2^23: ulp = 1 in [2^23, 2^24)

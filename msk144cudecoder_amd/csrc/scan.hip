@@ -297,15 +297,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
                     }
                 }
                 const float v = fmaf(sr, sr, si * si);
-                // strict >: the lowest position keeps exact ties.  Compare into an SGPR pair and select with the VOP3 form: the
-                // VCC form of v_cndmask measures 15-23 cycles per wave-instruction on gfx950 against 4.3
-                // (profiles/r02_valu_issue_microbench.txt); the value itself is a plain max.
-                unsigned long long better;
-                asm("v_cmp_gt_f32_e64 %[m], %[v], %[b]\n\t"
-                    "v_max_f32_e32 %[b], %[v], %[b]\n\t"
-                    "v_cndmask_b32_e64 %[x], %[x], %[i], %[m]"
-                    : [b] "+v"(best[p]), [x] "+v"(bidx[p]), [m] "=&s"(better)
-                    : [v] "v"(v), [i] "n"(i));
+                // strict >: the lowest position keeps exact ties
+                const bool better = v > best[p];
+                best[p] = __builtin_fmaxf(v, best[p]);
+                bidx[p] = better ? static_cast<uint32_t>(i) : bidx[p];
             }
             // every pattern's running maximum of this position is complete before the next position's loads may issue
             // (patterns 7 and 8 do not depend on all frames, so tying only the last sum would let the others pile up):

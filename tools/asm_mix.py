@@ -4,7 +4,9 @@ two line numbers of a hipcc -S listing.  usage: asm_mix.py file.s first_line las
 import re
 import sys
 
-FULL, HALF, QUARTER, VCCSEL = 2.45, 4.3, 8.2, 16.0
+# the VCC form of v_cndmask measured 15-23 cycles in the microbenchmark's 32-in-a-row pattern, but replacing such selects in the
+# kernels (scan fold, softbits sqrt) changed nothing: priced as any other half-rate instruction
+FULL, HALF, QUARTER, VCCSEL = 2.45, 4.3, 8.2, 4.3
 
 
 def cost(op, line):
