@@ -90,6 +90,7 @@ constexpr int kOutSpan = kOutPerThread * kPulseHalf;  // 66 consecutive outputs 
 constexpr int kOutColumns = kWindowSamples / kPulseHalf;  // 864 columns n = 6k + c
 constexpr int kOutGroups = (kOutColumns + kOutPerThread - 1) / kOutPerThread;  // 79 groups of six threads
 static_assert(kWindowSamples % kPulseHalf == 0 && kOutGroups * kPulseHalf <= kScanThreads, "thread -> (block of 66, residue) map");
+static_assert(kOutGroups % 3 != 0 && (kOutSpan * 3) % 32 == kPulseHalf, "u -> 3u mod groups is a bijection with consecutive LDS residues");
 // the last group's stream runs past the wrap pad: those samples only feed outputs beyond the window, which are dropped
 constexpr int kStreamPad = kOutSpan * (kOutGroups - 1) + kPulseHalf - 1 + kStream - (kWindowSamples + kWrapPad);
 static_assert(kStreamPad > 0 && kStreamPad < 64, "LDS buffer carries kStreamPad readable (unused) samples behind the wrap pad");
@@ -207,8 +208,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 
     // ---- 2. C[n0 + 6r], r = 0..10, by pulse decomposition (correlate_pulses); C then overwrites the window in place ----
     {
-        const int q = tid / kPulseHalf;
-        const int n0 = kOutSpan * q + (tid - q * kPulseHalf);
+        // Thread 6u + c takes output group q = 3u mod 79 (a bijection, 79 is prime): its stream starts at 66 q + c, and
+        // 66 * 3 = 6 mod 32, so the 32 lanes of a ds_read_b64 group read 32 consecutive residues mod 32 - conflict-free.
+        // With q = u the group stride is 66 = 2 mod 32 and every read (and every C store) is 3-way conflicted: the phase
+        // was LDS-bound (removal experiment: 3.8 ms for 2.5 ms of priced issue).
+        const int u = tid / kPulseHalf;
+        int q = 3 * u;
+        q -= q >= 2 * kOutGroups ? 2 * kOutGroups : (q >= kOutGroups ? kOutGroups : 0);
+        if(u >= kOutGroups) q = kOutGroups;  // idle threads
+        const int n0 = kOutSpan * q + (tid - u * kPulseHalf);
         float2 c[kOutPerThread];
         if(q < kOutGroups) correlate_pulses((lds_f2_ptr)(s_buf + n0), a.pp, c);
         __syncthreads();  // every thread has read its samples: C may overwrite the window
@@ -219,7 +227,37 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
             {
                 const int n = n0 + kPulseHalf * r;
                 if(n < kWindowSamples) s_buf[n] = c[r];
-                if(n < kRun) s_buf[kWindowSamples + n] = c[r];  // a run of the fold phase may cross the ring end
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2b. E[n] = C[n] + C[n + 336 mod N]: the two sync words of a frame, summed once per ring position ----
+    // S(pos, p) = sum over the pattern's frames of E[(pos + 864 m) mod N]: the fold then needs one load and one complex add per
+    // frame instead of two (the association (S + a) + b becomes S + (a + b): ~1e-7 relative on xb, like the other re-associations).
+    {
+        float2 e[kMixPerThread];
+#pragma unroll
+        for(int i = 0; i < kMixPerThread; i++)
+        {
+            const int n = tid + i * kScanThreads;
+            if((i + 1) * kScanThreads <= kWindowSamples || n < kWindowSamples)
+            {
+                int m = n + kSecondSyncSample;
+                if(m >= kWindowSamples) m -= kWindowSamples;
+                const float2 ca = s_buf[n], cb = s_buf[m];
+                e[i] = make_float2(ca.x + cb.x, ca.y + cb.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for(int i = 0; i < kMixPerThread; i++)
+        {
+            const int n = tid + i * kScanThreads;
+            if((i + 1) * kScanThreads <= kWindowSamples || n < kWindowSamples)
+            {
+                s_buf[n] = e[i];
+                if(n < kRun) s_buf[kWindowSamples + n] = e[i];  // a run of the fold phase may cross the ring end
             }
         }
     }
@@ -246,53 +284,46 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         const int in_slice = k * kRun < kSlicePositions - kRun ? k * kRun : kSlicePositions - kRun;  // last run: 245..255
         const uint32_t start = static_cast<uint32_t>(slice * kSlicePositions + in_slice);            // 0..5365
         typedef const volatile __attribute__((address_space(3))) v2f* lds_run_ptr;
-        lds_run_ptr pa[kFrames], pb[kFrames];
+        lds_run_ptr pe[kFrames];
 #pragma unroll
         for(int m = 0; m < kFrames; m++)
         {
             uint32_t ta = start + static_cast<uint32_t>(kFrameSamples * m);  // < 2 * ring
             ta = min(ta, ta - static_cast<uint32_t>(kWindowSamples));
             ta = min(ta, ta - static_cast<uint32_t>(kWindowSamples));        // start itself may exceed the ring (positions reach 5375)
-            uint32_t tb = ta + kSecondSyncSample;
-            tb = min(tb, tb - static_cast<uint32_t>(kWindowSamples));
-            pa[m] = (lds_run_ptr)(s_buf + ta);
-            pb[m] = (lds_run_ptr)(s_buf + tb);
+            pe[m] = (lds_run_ptr)(s_buf + ta);
         }
 #pragma unroll
         for(int i = 0; i < kRun; i++)
         {
-            float2 ca[kFrames], cb[kFrames];
+            float2 ef[kFrames];
 #pragma unroll
-            for(int m = 0; m < kFrames; m++)
-            {
-                ca[m] = as_float2(pa[m][i]);
-                cb[m] = as_float2(pb[m][i]);
-            }
+            for(int m = 0; m < kFrames; m++) ef[m] = as_float2(pe[m][i]);
             float sr = 0.0f, si = 0.0f;
 #pragma unroll
             for(int p = 0; p < D; p++)
             {
                 if(p == 0)
                 {
-                    sr = ca[0].x + cb[0].x;
-                    si = ca[0].y + cb[0].y;
+                    sr = ef[0].x;
+                    si = ef[0].y;
                 }
                 else if(p < kPatternBits)
                 {
-                    sr = (sr + ca[p].x) + cb[p].x;  // nested prefix masks: add frame p
-                    si = (si + ca[p].y) + cb[p].y;
+                    sr += ef[p].x;  // nested prefix masks: add frame p
+                    si += ef[p].y;
                 }
                 else
                 {
-                    sr = ca[0].x + cb[0].x;  // patterns 7 and 8 (100100, 100110) start from frame 0 again
-                    si = ca[0].y + cb[0].y;
+                    sr = ef[0].x;  // patterns 7 and 8 (100100, 100110) start from frame 0 again
+                    si = ef[0].y;
 #pragma unroll
                     for(int m = 1; m < kPatternBits; m++)
                     {
                         if(kPatternMask[p][m])
                         {
-                            sr = (sr + ca[m].x) + cb[m].x;
-                            si = (si + ca[m].y) + cb[m].y;
+                            sr += ef[m].x;
+                            si += ef[m].y;
                         }
                     }
                 }
