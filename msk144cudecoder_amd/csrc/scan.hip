@@ -5,7 +5,7 @@
 // pattern, 42 taps x 2*num_avg folded samples; here the linearity of the correlation is used:
 //
 //   C[n]      = sum_k conj(cdat2[(n+k) mod N]) * cb42[k]          one pass over the window
-//   S(pos,p)  = sum_{m in mask_p} C[(pos+864m) mod N] + C[(pos+864m+336) mod N]
+//   S(pos,p)  = sum_{m in mask_p} C[(pos+864m) mod N] + C[(pos+864m+336) mod N]   = sum_{m in mask_p} E[(pos+864m) mod N]
 //   xb        = |S|
 //
 // cdat2 is the window mixed down with exactly the reference's float phase (scan_kernel.cuh:54), so
@@ -13,18 +13,22 @@
 // (~1e-6 relative on xb).  Patterns 0..5 are nested prefixes (msk_context.cuh:231-236): S is
 // accumulated across them.
 //
-// Phases (LDS: one 5184+41 complex buffer, 44 KB per workgroup -> 3 workgroups per CU):
+// Phases (LDS: one 5184+41 complex buffer, 44 KB per workgroup -> 3 workgroups of 8 waves per CU):
 //  1. mix the window into LDS (custom ~25-instruction sincos, mix.h);
 //  2. C[n] by pulse decomposition (correlate_pulses below): a thread owns eleven outputs spaced by six, which share
 //     seventeen half-pulse sums built from the 102 samples it streams - 187 multiply-adds + 93 adds of complex values per
 //     thread instead of one 42-tap sum per output (847).  After a barrier C overwrites the window in place;
-//  3. fold + |S|^2 per pattern; each wave takes 128-position half-slices, pre-reduces the lane's two
-//     positions, then one DPP max + ballot per (half-slice, pattern).  No barrier in this phase (the
-//     reference has 4 per slice).  Lowest position wins exact ties, as the reference's strict-> trees;
-//  4. xb = sqrt (correctly rounded) of the half-slice maxima in parallel; then one wave, lane = 8*pattern +
-//     slot, runs the reference's 8-slot replacement rule in slice order (scan_kernel.cuh:276-353): slice
-//     maximum = better of two halves, arg-min over a pattern's 8 slots by three DPP min steps + ballot
-//     (lowest slot wins ties), conditional replace.  21 short steps instead of a 1300-instruction serial tail.
+//  2b. E[n] = C[n] + C[n + 336]: the two sync words of a frame, once per ring position (in place, one more barrier), so that
+//     S(pos, p) = sum_m E[(pos + 864 m) mod N] costs the fold one load and one add per frame;
+//  3. fold + |S|^2 per pattern along RUNS: a lane walks eleven consecutive positions of one 256-position slice and keeps a
+//     running maximum and its position per pattern (strict >: the lowest position keeps exact ties, as the reference's
+//     strict-> trees) - one compare, one max and one select per (position, pattern) and no cross-lane reduction, where
+//     the earlier form (positions across lanes, a 6-step DPP max + two ballots per 128 positions and pattern) spent half
+//     of the phase on reductions.  24 runs cover a slice; after a barrier they meet through the freed window buffer and
+//     one thread per (pattern, slice) takes the first strict maximum in position order;
+//  4. xb = sqrt (correctly rounded) of the 21 x D slice maxima in parallel; then one wave, lane = 8*pattern + slot, runs the
+//     reference's 8-slot replacement rule in slice order (scan_kernel.cuh:276-353): arg-min over a pattern's 8 slots by
+//     three DPP min steps + ballot (lowest slot wins ties), conditional replace.
 #include "msk144_kernels.h"
 #include "mix.h"
 #include "wave64.h"
