@@ -307,7 +307,7 @@ def run_worker(args) -> int:
         achieved = B_ALG_PER_CANDIDATE * cand_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # Static PMC counters (separate rocprofv3 --pmc passes, committed under profiles/): used only when they were
         # collected on exactly these kernel sources and this workload; labelled with their origin.
-        traffic, valu, static = None, None, None
+        traffic, valu, lds, static = None, None, None, None
         if os.path.exists(COUNTERS_FILE) and channels == CHANNELS_PER_GPU and Backend is HipBackend:
             try:
                 cj = json.load(open(COUNTERS_FILE))
@@ -318,11 +318,17 @@ def run_worker(args) -> int:
                             "peak_note": "256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 VALU op (MI355X_MICROARCH.md); transcendentals and "
                                          "v_pk_* cost more than one slot, see profiles/r02_valu_issue_microbench.txt",
                             "static": static}
+                    lds = {"unit": "busy fraction of the LDS array (SQ_LDS_IDX_ACTIVE cycles / (256 CUs x 2.4 GHz x measured stage time))",
+                           "static": static}
                     for k in ("scan", "softbits", "ldpc"):
                         n_valu = cj.get("kernels", {}).get(k + "_kernel", {}).get("SQ_INSTS_VALU")
                         if n_valu and stage[k][0] > 0:
                             rate = n_valu / (stage[k][0] * 1e-3)
                             valu[k + "_kernel"] = {"achieved": rate, "frac": rate / VALU_PEAK_WAVE_INSTR}
+                        n_lds = cj.get("kernels", {}).get(k + "_kernel", {}).get("SQ_LDS_IDX_ACTIVE")
+                        if n_lds and stage[k][0] > 0:
+                            lds[k + "_kernel"] = {"frac": n_lds / (256 * 2.4e9 * stage[k][0] * 1e-3),
+                                                  "conflict_share": cj["kernels"][k + "_kernel"].get("SQ_LDS_BANK_CONFLICT", 0.0) / n_lds}
                 else:
                     static = "profiles/counters.json is stale for these kernel sources: traffic/valu_issue omitted"
             except Exception as e:  # noqa: BLE001
@@ -343,6 +349,7 @@ def run_worker(args) -> int:
                          "candidates_per_launch": cand_per_launch,
                          "note": "path is VALU/LDS-bound (SURVEY.md 8d); HBM fraction reported as measured"},
             "valu_issue": valu,
+            "lds_array": lds,
             "stage_ms": {n: round(stage[n][0], 4) for n in T_NAMES},
             "decodes_last_step": int(len(last)), "channels_decoded_last_step": chans_decoded, "crc13_false_positives_last_step": wrong,
         }

@@ -29,14 +29,21 @@ namespace
 
 constexpr int kLdpcThreads = 256;
 constexpr int kLdpcWaves = kLdpcThreads / 64;
-constexpr int kTStride = kTileRowStride;  // T[slot][lane of check] row stride (ldpc_layout.h)
+constexpr int kTStride = kTileRowStride;  // backward tile Tb[round][lane of check] row stride (ldpc_layout.h)
+// Per-wave LDS: forward tile Tf[3h + i][lane] (bit-major: the tanh of the edge instruction i of half h handles in lane l), one
+// cell holding the constant 1.0 (the missing eleventh factor of the degree-10 checks), then the backward tile Tb.
+constexpr int kFwdCells = 2 * kEdgesPerBit * 64;   // 384
+constexpr int kOneCell = kFwdCells;                // Tf[384] = 1.0
+constexpr int kBwdBase = kFwdCells + 8;            // Tb starts here (floats)
+constexpr int kTileFloats = kBwdBase + kMaxCheckDegree * kTStride;
 
 // Edge tables derived at compile time from the check-major graph and the lane layout of ldpc_layout.h (bit -> lane, check ->
 // lane and first-edge order were annealed offline so that the edge-side scatter/gather through the tile is at most 2-way
 // conflicted: 9 instead of 18 extra LDS cycles per iteration and direction; 2-way costs a ds_write_b32 nothing).
 struct EdgeTables
 {
-    uint16_t cell[2][64][kEdgesPerBit];  // tile cell of the edge handled by instruction i of (half h, lane l)
+    uint16_t cell[2][64][kEdgesPerBit];  // backward-tile cell (relative to Tb) of the edge handled by instruction i of (half h, lane l)
+    uint16_t fwd[64][kMaxCheckDegree];   // forward-tile cell check lane L reads in round r (kOneCell where the check has no edge)
     uint64_t hlo[64];                    // parity-check row of the lane's check as masks over ballot(half 0), ballot(half 1)
     uint64_t hhi[64];
     uint8_t full[64];                    // the lane's check has 11 bits (ldpc_context.cuh:160-163)
@@ -56,6 +63,7 @@ constexpr EdgeTables make_edge_tables()
         t.hlo[l] = 0;
         t.hhi[l] = 0;
         t.full[l] = 0;
+        for(int r = 0; r < kMaxCheckDegree; r++) t.fwd[l][r] = kOneCell;
     }
     for(int c = 0; c < kChecks; c++)
     {
@@ -66,7 +74,7 @@ constexpr EdgeTables make_edge_tables()
             const int n = kCheckBits[c][j];
             if(n < 0) continue;
             e_check[n][cnt[n]] = static_cast<int8_t>(c);  // edges of a bit in ascending check order = the reference's k
-            e_slot[n][cnt[n]] = static_cast<int8_t>(j);
+            e_slot[n][cnt[n]] = static_cast<int8_t>(kRoundOfSlot[c][j]);  // the round in which the check lane handles this edge
             cnt[n]++;
             const int p = t.pos_of_bit[n];
             if(p < 64) t.hlo[cl] |= (1ull << p);
@@ -82,6 +90,7 @@ constexpr EdgeTables make_edge_tables()
                 // instructions 0 and 1 may take the bit's first two edges in either order: (tov0 + tov1) + tov2 is commutative in them
                 const int k = (i < 2 && kSwapFirstEdges[n]) ? 1 - i : i;
                 t.cell[h][l][i] = static_cast<uint16_t>(e_slot[n][k] * kTileRowStride + kLaneOfCheck[e_check[n][k]]);
+                t.fwd[kLaneOfCheck[e_check[n][k]]][e_slot[n][k]] = static_cast<uint16_t>((h * kEdgesPerBit + i) * 64 + l);
             }
         }
     return t;
@@ -180,7 +189,7 @@ __device__ __forceinline__ uint32_t crc13_96(uint64_t m_hi64, uint32_t m_lo32)
 
 __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st)
 {
-    __shared__ float s_t[kLdpcWaves][kMaxCheckDegree * kTStride];
+    __shared__ float s_t[kLdpcWaves][kTileFloats];
 
     const int ch = st.ch0 + blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -198,19 +207,20 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 #pragma unroll
     for(int h = 0; h < 2; h++)
 #pragma unroll
-        for(int k = 0; k < kEdgesPerBit; k++) e_addr[h][k] = kEdges.cell[h][lane][k];
+        for(int k = 0; k < kEdgesPerBit; k++) e_addr[h][k] = kBwdBase + kEdges.cell[h][lane][k];
+    // forward gather: the cell this check lane reads in round r (lanes >= 38 read the constant)
+    const float* f_addr[kMaxCheckDegree];
+#pragma unroll
+    for(int r = 0; r < kMaxCheckDegree; r++) f_addr[r] = T + kEdges.fwd[lane][r];
     const uint64_t hlo = kEdges.hlo[lane];  // zero for lanes >= 38
     const uint64_t hhi = kEdges.hhi[lane];
-    const bool my_full = kEdges.full[lane] != 0;
-    const uint64_t full_mask = __ballot(my_full && lane < kChecks);
     const int bit_of[2] = {kBitOfLane[0][lane], kBitOfLane[1][lane]};
-    const int src_lo = kEdges.pos_of_bit[lane], src_hi = kEdges.pos_of_bit[lane + 64];  // ballot positions of codeword bits lane, lane + 64
 
     // LDS byte address of this wave's tile, for the M0-relative column stores
     const uint32_t tile_m0 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) float*)T)));
 
-    // slot 10 of the degree-10 checks is never written: it stays 1.0 so that full-column products ignore it
-    for(int t = lane; t < kMaxCheckDegree * kTStride; t += 64) T[t] = 1.0f;
+    // the eleventh factor of the degree-10 checks
+    if(lane == 0) T[kOneCell] = 1.0f;
 
     // Software pipeline over this wave's codewords: the index entry of codeword n+2 and the two LLRs of codeword n+1 are
     // fetched while codeword n iterates, so a codeword starts without the two dependent global-memory latencies
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                 const bool bad1 = cw[1] ? !(llr[1] > 0.0f) : !(llr[1] <= 0.0f);
                 const int nhard = __popcll(__ballot(bad0)) + __popcll(__ballot(bad1));
                 // back to the codeword's own bit order: lane n fetches bits n and n + 64 from the layout-ordered ballots
+                const int src_lo = kEdges.pos_of_bit[lane], src_hi = kEdges.pos_of_bit[lane + 64];  // ballot positions of codeword bits lane, lane + 64 (table read only here: rare path)
                 const uint64_t w_lo = (src_lo & 64) ? hi : lo;
                 const uint64_t w_hi = (src_hi & 64) ? hi : lo;
                 const uint64_t c_lo = __ballot(((w_lo >> (src_lo & 63)) & 1ull) != 0);
@@ -299,57 +310,56 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             }
             if(iter == kLdpcIterations - 1) break;  // the reference's last update is never consumed
 
-            // bit -> check messages, tanh once per edge (ldpc_kernel.cuh:225-241)
+            // bit -> check messages, tanh once per edge (ldpc_kernel.cuh:225-241), into the bit-major forward tile: cell
+            // (3h + k)*64 + lane is M0 + offset + 4*lane, so the six stores are ds_write_addtid_b32 (no address VGPR: 2.25
+            // LDS cycles each against 4.25 for ds_write_b32, tools/ubench/lds_exec_groups.hip) and never conflict
+            {
+                float th[2][kEdgesPerBit];
 #pragma unroll
-            for(int h = 0; h < 2; h++)
+                for(int h = 0; h < 2; h++)
 #pragma unroll
-                for(int k = 0; k < kEdgesPerBit; k++)
-                {
-                    const float toc = zn[h] - tov[h][k];
-                    T[e_addr[h][k]] = tanh_neg_half_scaled(toc);
-                }
+                    for(int k = 0; k < kEdgesPerBit; k++) th[h][k] = tanh_neg_half_scaled(zn[h] - tov[h][k]);
+                static_assert(kEdgesPerBit == 3, "six forward stores below");
+                asm volatile("s_mov_b32 m0, %6\n\t"
+                             "s_nop 0\n\t"  // SALU write of M0 -> LDS add-TID instruction: one wait state
+                             "ds_write_addtid_b32 %0 offset:0\n\t"
+                             "ds_write_addtid_b32 %1 offset:256\n\t"
+                             "ds_write_addtid_b32 %2 offset:512\n\t"
+                             "ds_write_addtid_b32 %3 offset:768\n\t"
+                             "ds_write_addtid_b32 %4 offset:1024\n\t"
+                             "ds_write_addtid_b32 %5 offset:1280"
+                             :
+                             : "v"(th[0][0]), "v"(th[0][1]), "v"(th[0][2]), "v"(th[1][0]), "v"(th[1][1]), "v"(th[1][2]), "s"(tile_m0)
+                             : "memory");
+            }
             __builtin_amdgcn_wave_barrier();
 
             // check node c (lane c): column T[0..10][c] -> leave-one-out products, in place
             if(lane < kChecks)
             {
+                // round r: the tanh of this check's edge of colour r, gathered from the bit-major tile; the rounds are an edge
+                // colouring of (check, bit lane mod 32), so the 32 lanes of a group never share a bank (ldpc_layout.h)
                 float t[kMaxCheckDegree];
-                asm volatile("s_mov_b32 m0, %11\n\t"
-                             "s_nop 0\n\t"
-                             "ds_read_addtid_b32 %0 offset:%c12\n\t"
-                             "ds_read_addtid_b32 %1 offset:%c13\n\t"
-                             "ds_read_addtid_b32 %2 offset:%c14\n\t"
-                             "ds_read_addtid_b32 %3 offset:%c15\n\t"
-                             "ds_read_addtid_b32 %4 offset:%c16\n\t"
-                             "ds_read_addtid_b32 %5 offset:%c17\n\t"
-                             "ds_read_addtid_b32 %6 offset:%c18\n\t"
-                             "ds_read_addtid_b32 %7 offset:%c19\n\t"
-                             "ds_read_addtid_b32 %8 offset:%c20\n\t"
-                             "ds_read_addtid_b32 %9 offset:%c21\n\t"
-                             "ds_read_addtid_b32 %10 offset:%c22\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10])
-                             : "s"(tile_m0), "n"(0 * kTStride * 4), "n"(1 * kTStride * 4), "n"(2 * kTStride * 4), "n"(3 * kTStride * 4), "n"(4 * kTStride * 4), "n"(5 * kTStride * 4),
-                               "n"(6 * kTStride * 4), "n"(7 * kTStride * 4), "n"(8 * kTStride * 4), "n"(9 * kTStride * 4), "n"(10 * kTStride * 4)
-                             : "memory");
+#pragma unroll
+                for(int r = 0; r < kMaxCheckDegree; r++) t[r] = *f_addr[r];
                 float pre[kMaxCheckDegree];  // pre[j] = t0*...*t(j-1)
                 pre[0] = 1.0f;
 #pragma unroll
                 for(int j = 1; j < kMaxCheckDegree; j++) pre[j] = pre[j - 1] * t[j - 1];
                 float suf = -1.0f;           // -(t(j+1)*...*t10): the column is stored NEGATED, ready for platanh(-product)
                 float out[kMaxCheckDegree];
-                uint64_t exec_save;
 #pragma unroll
                 for(int j = kMaxCheckDegree - 1; j >= 0; j--)
                 {
                     out[j] = pre[j] * suf;
                     suf *= t[j];
                 }
-                // The column store is base + 4 j stride + 4 lane: ds_write_addtid_b32 takes that address from M0 + offset + 4*lane
-                // and moves no address VGPR to the LDS - 2 cycles per store instead of ds_write_b32's 4 (MI355X_MICROARCH.md, LDS).
+                // The column store is base + 4 r stride + 4 lane: ds_write_addtid_b32 takes that address from M0 + offset + 4*lane
+                // and moves no address VGPR to the LDS.  A degree-10 check also stores the product of its empty round: no edge reads it.
                 static_assert(kMaxCheckDegree == 11, "eleven column stores below");
-                asm volatile("s_mov_b32 m0, %12\n\t"
+                asm volatile("s_mov_b32 m0, %11\n\t"
                              "s_nop 0\n\t"  // SALU write of M0 -> LDS add-TID instruction: one wait state
+                             "ds_write_addtid_b32 %0 offset:%c12\n\t"
                              "ds_write_addtid_b32 %1 offset:%c13\n\t"
                              "ds_write_addtid_b32 %2 offset:%c14\n\t"
                              "ds_write_addtid_b32 %3 offset:%c15\n\t"
@@ -359,15 +369,12 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                              "ds_write_addtid_b32 %7 offset:%c19\n\t"
                              "ds_write_addtid_b32 %8 offset:%c20\n\t"
                              "ds_write_addtid_b32 %9 offset:%c21\n\t"
-                             "ds_write_addtid_b32 %10 offset:%c22\n\t"
-                             "s_mov_b64 %0, exec\n\t"
-                             "s_and_b64 exec, exec, %24\n\t"   // slot 10 exists only in the degree-11 checks; the others keep its constant 1.0
-                             "ds_write_addtid_b32 %11 offset:%c23\n\t"
-                             "s_mov_b64 exec, %0"
-                             : "=&s"(exec_save)
+                             "ds_write_addtid_b32 %10 offset:%c22"
+                             :
                              : "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7]), "v"(out[8]), "v"(out[9]), "v"(out[10]),
-                               "s"(tile_m0), "n"(0 * kTStride * 4), "n"(1 * kTStride * 4), "n"(2 * kTStride * 4), "n"(3 * kTStride * 4), "n"(4 * kTStride * 4), "n"(5 * kTStride * 4),
-                               "n"(6 * kTStride * 4), "n"(7 * kTStride * 4), "n"(8 * kTStride * 4), "n"(9 * kTStride * 4), "n"(10 * kTStride * 4), "s"(full_mask)
+                               "s"(tile_m0), "n"((kBwdBase + 0 * kTStride) * 4), "n"((kBwdBase + 1 * kTStride) * 4), "n"((kBwdBase + 2 * kTStride) * 4),
+                               "n"((kBwdBase + 3 * kTStride) * 4), "n"((kBwdBase + 4 * kTStride) * 4), "n"((kBwdBase + 5 * kTStride) * 4), "n"((kBwdBase + 6 * kTStride) * 4),
+                               "n"((kBwdBase + 7 * kTStride) * 4), "n"((kBwdBase + 8 * kTStride) * 4), "n"((kBwdBase + 9 * kTStride) * 4), "n"((kBwdBase + 10 * kTStride) * 4)
                              : "memory");
             }
             __builtin_amdgcn_wave_barrier();

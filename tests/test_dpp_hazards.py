@@ -114,7 +114,7 @@ def test_no_dpp_hazard_in_compiled_kernels(src, extra):
     if src in ("scan.hip", "softbits.hip"):
         assert checked >= 16         # the kernels that carry the hand-written DPP reductions really were inspected
     if src == "ldpc.hip":
-        assert checked >= 22         # eleven add-TID column loads and eleven stores
+        assert checked >= 17         # six add-TID forward stores and eleven column stores
 
 
 def test_m0_is_only_touched_inside_our_asm_blocks_of_the_ldpc_kernel():

@@ -1,7 +1,7 @@
-"""csrc/ldpc_layout.h (the annealed lane layout of the BP message tile) checked on the CPU: the tables are bijections and, under
-the LDS bank rules of MI355X_MICROARCH.md (ds_read_b32 / ds_write_b32: two groups of 32 lanes, 32 banks of 4 bytes, one extra
-cycle per extra distinct address on a bank), no edge-side instruction is worse than 2-way conflicted and the totals are the ones
-the header quotes; the check side (consecutive lanes on consecutive cells) is conflict-free for any stride."""
+"""csrc/ldpc_layout.h (the searched lane layout of the BP messages) checked on the CPU: the tables are bijections and, under the
+LDS bank rules of MI355X_MICROARCH.md (ds_read_b32: two groups of 32 lanes, 32 banks of 4 bytes, N distinct addresses on one bank
+= N cycles), the forward gather of the check lanes is conflict-free in every round (the rounds are a proper edge colouring of
+(check, bit lane mod 32)) and the backward gather of the bit lanes has exactly the extra cycles the header quotes."""
 import os
 import re
 
@@ -22,6 +22,7 @@ S = int(re.search(r"kTileRowStride = (\d+);", HDR).group(1))
 BITS = np.array(_table("kBitOfLane")).reshape(2, 64)
 SWAP = np.array(_table("kSwapFirstEdges"))
 LOC = np.array(_table("kLaneOfCheck"))
+ROUND = np.array(_table("kRoundOfSlot")).reshape(38, 11)
 ROWS = [[n for n in r if n >= 0] for r in P.CHECK_BITS]
 EDGES = [[] for _ in range(128)]
 for c, r in enumerate(ROWS):
@@ -29,7 +30,8 @@ for c, r in enumerate(ROWS):
         EDGES[n].append((j, c))
 
 
-def edge_conflicts(bits, swap, loc, stride):
+def backward_conflicts(bits, swap, loc, rounds, stride):
+    """Extra LDS cycles of the six gather loads of the bit lanes (cell = round * stride + lane of the check)."""
     total, worst = 0, 0
     for h in range(2):
         for i in range(3):
@@ -39,11 +41,29 @@ def edge_conflicts(bits, swap, loc, stride):
                     n = bits[h][lane]
                     k = 1 - i if (i < 2 and swap[n]) else i
                     j, c = EDGES[n][k]
-                    banks.append((j * stride + loc[c]) % 32)
+                    banks.append((rounds[c][j] * stride + loc[c]) % 32)
                 m = int(np.bincount(banks, minlength=32).max())
                 total += m - 1
                 worst = max(worst, m)
     return total, worst
+
+
+def forward_conflicts(bits, loc, rounds):
+    """Extra LDS cycles of the eleven gather loads of the check lanes (cell = (3h + i) * 64 + lane of the bit: bank = lane % 32)."""
+    lane_of_bit = {int(bits[h][l]): l for h in range(2) for l in range(64)}
+    total = 0
+    for r in range(11):
+        for g in range(2):
+            cells = {}
+            for c, row in enumerate(ROWS):
+                if (loc[c] >= 32) != bool(g):
+                    continue
+                for j, n in enumerate(row):
+                    if rounds[c][j] == r:
+                        cells.setdefault(lane_of_bit[n] % 32, set()).add(n)
+            if cells:
+                total += max(len(v) for v in cells.values()) - 1
+    return total
 
 
 def test_tables_are_bijections():
@@ -51,22 +71,24 @@ def test_tables_are_bijections():
     assert sorted(LOC.tolist()) == list(range(38))
     assert set(SWAP.tolist()) <= {0, 1} and len(SWAP) == 128
     assert S >= 38                                     # rows of 38 check lanes do not overlap
-    cells = {j * S + LOC[c] for c, r in enumerate(ROWS) for j in range(len(r))}
-    assert len(cells) == 384                            # one cell per Tanner-graph edge
+    for c in range(38):
+        assert sorted(ROUND[c].tolist()) == list(range(11))   # every check visits every round once (one is empty for degree 10)
+    cells = {int(ROUND[c][j]) * S + int(LOC[c]) for c, r in enumerate(ROWS) for j in range(len(r))}
+    assert len(cells) == 384                            # one backward cell per Tanner-graph edge
 
 
-def test_edge_side_is_at_most_two_way_conflicted():
-    total, worst = edge_conflicts(BITS, SWAP, LOC, S)
-    quoted = re.search(r"direction: (\d+) \(worst instruction (\d+)-way\); the natural layout\s*//\s*\(bit n in lane n % 64, stride 40\) has (\d+) \((\d+)-way\)", HDR)
+def test_forward_gather_is_conflict_free():
+    assert forward_conflicts(BITS, LOC, ROUND) == 0
+    natural = forward_conflicts(np.arange(128).reshape(2, 64), np.arange(38), np.tile(np.arange(11), (38, 1)))
+    quoted = re.search(r"Forward gather: (\d+) extra LDS cycles per iteration \(rounds = row order on the natural layout: (\d+)\)", HDR)
     assert quoted, "header comment changed"
-    assert (total, worst) == (int(quoted.group(1)), int(quoted.group(2)))
-    assert worst <= 2 and total <= 9
-    natural = edge_conflicts(np.arange(128).reshape(2, 64), np.zeros(128, dtype=int), np.arange(38), 40)
-    assert natural == (int(quoted.group(3)), int(quoted.group(4))) and natural[0] >= 2 * total
+    assert (0, natural) == (int(quoted.group(1)), int(quoted.group(2))) and natural > 0
 
 
-def test_check_side_is_conflict_free():
-    for j in range(11):
-        cells = [j * S + lane for lane in range(38)]    # check lane l walks column cell j*S + l
-        for group in (cells[:32], cells[32:]):
-            assert len({c % 32 for c in group}) == len(group)
+def test_backward_gather_matches_the_quoted_conflicts():
+    total, worst = backward_conflicts(BITS, SWAP, LOC, ROUND, S)
+    quoted = re.search(r"Backward gather: (\d+) extra LDS cycles per iteration \(natural layout, bit n in lane n % 64, rounds = row order: (\d+)\)", HDR)
+    assert quoted, "header comment changed"
+    assert total == int(quoted.group(1)) and worst <= 3
+    natural = backward_conflicts(np.arange(128).reshape(2, 64), np.zeros(128, dtype=int), np.arange(38), np.tile(np.arange(11), (38, 1)), S)
+    assert natural[0] == int(quoted.group(2)) and natural[0] > total
