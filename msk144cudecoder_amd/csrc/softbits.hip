@@ -336,20 +336,15 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             sum_sav = t;
             sum_s2av = q;
         }
-        const float sav = div_by_const<144>(sum_sav);    // correctly rounded, like the reference's division
-        const float s2av = div_by_const<144>(sum_s2av);
-        const float ssig = f32_sqrt(f32_sub(s2av, f32_mul(sav, sav)));
+        // sav, s2av, ssig and the scale are wave-uniform numbers formed from two 144-term sums that already differ from the
+        // reference's by ~1e-7 relative (different association): rounding them correctly on top (a Markstein division by 144,
+        // the library's 15-instruction sqrt, a Newton step on the reciprocal) bought nothing measurable and cost ~35 uniform
+        // VALU instructions per candidate.  One-ulp hardware forms: x * (1/144), v_sqrt_f32, 2 * v_rcp_f32.
+        const float sav = sum_sav * (1.0f / 144.0f);
+        const float s2av = sum_s2av * (1.0f / 144.0f);
+        const float ssig = __builtin_amdgcn_sqrtf(fmaf(-sav, sav, s2av));
         const float sigma = 0.60f;
-        const float den = f32_mul(f32_mul(ssig, sigma), sigma);
-        // 2/den: reciprocal + one Newton step on the residual (Markstein form with a runtime divisor):
-        // correctly rounded except in rare double-rounding cases, 4 instructions instead of the ~10 of v_div_*
-        float scale;
-        {
-            const float r = __builtin_amdgcn_rcpf(den);
-            const float q = 2.0f * r;
-            const float e = fmaf(-q, den, 2.0f);
-            scale = fmaf(e, r, q);
-        }
+        const float scale = 2.0f * __builtin_amdgcn_rcpf(ssig * (sigma * sigma));
 
         // ---- sync-word disagreements (softbits_kernel.cuh:214-241): bits 0..7 and 56..63 ----
         const int hard = (soft[0] < 0.0f) ? -1 : 1;
