@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             // previous slot, and group 0 takes group 143 (slot 2, lane 15): the frame is circular
             float in = dpp_f32<kDppWaveShr1>(start[s]);
             const float edge = (s == 0) ? readlane_f32(start[kSlots - 1], kGroups - 64 * (kSlots - 1) - 1) : readlane_f32(start[s - 1], 63);
-            if(lane == 0) in = edge;
+            asm("v_writelane_b32 %0, %1, 0" : "+v"(in) : "s"(edge));  // lane 0 <- edge (one instruction instead of v_mov + v_cndmask)
             const float sb = in + fmaf(u2[s].y, b_i, u2[s].x * b_r);
             soft[s] = (s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) ? 0.0f : sb;
         }
