@@ -8,37 +8,33 @@
 namespace msk144
 {
 
-// sin and cos of a float angle |phi| < ~1e4 rad, about 1.5 ulp: two-constant Cody-Waite reduction by
-// pi/2 with FMA, cephes minimax polynomials on [-pi/4, pi/4].  Replaces ocml sincosf (~4x the
-// instructions); the reference uses CUDA's sincosf, itself ~2 ulp.
-// The quadrant fix-up is pure bit arithmetic (no v_cmp / v_cndmask / v_rndne / v_cvt, all half rate,
-// profiles/r02_valu_issue_microbench.txt): k = rint(phi*2/pi) comes from the 1.5*2^23 add trick, whose float bits also hold
-// k mod 4, and the swap / sign flips are bit operations.
+// sin and cos of a float angle |phi| < ~1e4 rad, absolute error <= 1.5e-7 (about 1.3 ulp of 1.0; tools-side check: numpy
+// emulation of this float32/FMA sequence against double precision on 2 M points): two-constant Cody-Waite reduction by PI
+// with FMA, minimax polynomials on [-pi/2, pi/2] (sin: odd, degree 9; cos: even, degree 10).  Reducing by pi instead of
+// pi/2 trades four extra polynomial terms for the whole quadrant fix-up: an odd multiple of pi only flips BOTH signs, one
+// shift and two XORs, where the swap of sin and cos by quadrant cost thirteen bit operations.  k = rint(phi/pi) comes from
+// the 1.5*2^23 add trick, whose float bits also hold k's parity.  Replaces ocml sincosf (~5x the instructions); the
+// reference uses CUDA's sincosf, itself ~2 ulp.
 __device__ __forceinline__ void sincos_reduced(float phi, float& sn, float& cs)
 {
     constexpr float kRound = 12582912.0f;                             // 1.5 * 2^23: ulp = 1 in [2^23, 2^24)
-    const float kb = fmaf(phi, 0.636619772367581343f, kRound);        // 2/pi; low mantissa bits = k (two's complement)
+    const float kb = fmaf(phi, 0.318309886183790672f, kRound);        // 1/pi; low mantissa bit = parity of k
     const float k = kb - kRound;                                      // exact
-    float r = fmaf(-k, 1.57079637050628662109375f, phi);             // fl(pi/2)
-    r = fmaf(-k, -4.37113900018624283e-8f, r);                        // pi/2 - fl(pi/2)
+    float r = fmaf(-k, 3.1415927410125732f, phi);                        // fl(pi)
+    r = fmaf(-k, -8.742277657347586e-08f, r);                       // pi - fl(pi)
     const float z = r * r;
-    float sp = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    sp = fmaf(sp, z, -1.6666654611e-1f);
+    float sp = fmaf(2.635400051076431e-06f, z, -0.00019823024922516197f);
+    sp = fmaf(sp, z, 0.008333245292305946f);
+    sp = fmaf(sp, z, -0.1666666567325592f);
     const float s_r = fmaf(r * z, sp, r);
-    float cp = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    cp = fmaf(cp, z, 4.166664568298827e-2f);
-    const float c_r = fmaf(z * z, cp, fmaf(-0.5f, z, 1.0f));
-    const uint32_t q = __builtin_bit_cast(uint32_t, kb);
-    const uint32_t su = __builtin_bit_cast(uint32_t, s_r), cu = __builtin_bit_cast(uint32_t, c_r);
-    const uint32_t swap = 0u - (q & 1u);                              // odd quadrant: sin <-> cos
-    uint32_t s = (cu & swap) | (su & ~swap);                          // v_bfi_b32
-    uint32_t c = (su & swap) | (cu & ~swap);
-    // quadrant signs: sin negative for q = 2,3 (bit 1); cos negative for q = 1,2 (bit 1 xor bit 0)
-    const uint32_t t = q << 30;
-    s ^= t & 0x80000000u;
-    c ^= (t ^ (t << 1)) & 0x80000000u;
-    sn = __builtin_bit_cast(float, s);
-    cs = __builtin_bit_cast(float, c);
+    float cp = fmaf(-2.6325329827159294e-07f, z, 2.4776121790637262e-05f);
+    cp = fmaf(cp, z, -0.001388867967762053f);
+    cp = fmaf(cp, z, 0.0416666604578495f);
+    cp = fmaf(cp, z, -0.5f);
+    const float c_r = fmaf(cp, z, 1.0f);
+    const uint32_t flip = __builtin_bit_cast(uint32_t, kb) << 31;      // k odd: sin(r + k pi) = -sin r, cos(r + k pi) = -cos r
+    sn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s_r) ^ flip);
+    cs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, c_r) ^ flip);
 }
 
 // x / 12000 correctly rounded without the hardware division sequence (Markstein): with r = RN(1/d),
