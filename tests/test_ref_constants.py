@@ -206,4 +206,4 @@ def test_platanh_constants_and_branch_free_first_breakpoint():
 def test_softbits_normalisation_constants():
     sb = _src("softbits.hip")
     assert float(re.search(r"const float sigma = ([\d.]+)f;", sb).group(1)) == REF["softbits_sigma"]
-    assert "div_by_const<144>" in sb and REF["softbits_mean_divisor"] == 144.0
+    assert "(1.0f / 144.0f)" in sb and REF["softbits_mean_divisor"] == 144.0
