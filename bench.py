@@ -48,14 +48,22 @@ COUNTERS_FILE = os.path.join(ROOT, "profiles", "counters.json")
 
 
 def kernel_source_sha() -> str:
-    """Hash of the kernel sources; profiles/counters.json records the one it was collected on, so stale
-    static counters are never mixed with live timings."""
+    """Hash of the kernel sources' CODE (// comments and blank space dropped, so that rewording a comment does not orphan the
+    counters); profiles/counters.json records the one it was collected on, so stale static counters are never mixed with live
+    timings."""
     csrc = os.path.join(ROOT, "msk144cudecoder_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".hip", ".h", ".cpp")):
             h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
+            for line in open(os.path.join(csrc, name), "r", encoding="utf-8"):
+                cut = line.find("//")
+                while cut > 0 and line[:cut].count('"') % 2 == 1:      # "//" inside a string literal (asm text, URLs)
+                    cut = line.find("//", cut + 2)
+                code = (line if cut < 0 else line[:cut]).strip()
+                if code:
+                    h.update(" ".join(code.split()).encode())
+                    h.update(b"\n")
     return h.hexdigest()[:16]
 
 

@@ -2,16 +2,18 @@
 //
 // Replaces ldpc_kernel (ldpc_kernel.cuh:9-249).  The reference runs one 128-thread
 // block per gated candidate; here ONE 64-lane wave decodes one codeword (2 bits, 6 edges per lane; which bits a lane
-// owns and which lane walks which check: ldpc_layout.h, annealed for LDS bank conflicts):
+// owns, which lane walks which check and in which round it meets which edge: ldpc_layout.h, generated for the LDS banks):
 //   * hard decisions live in two 64-bit ballot masks (SGPRs); the 38 parity checks are
 //     popcount(cw & H_row) on the 38 check lanes, the hard-error count is a popcount of a ballot -
 //     no 11x38 byte scatter, no block reductions, no barriers;
 //   * tanh(-toc/2) is evaluated once per edge (384 per iteration, the reference recomputes 3840) with
-//     a 5-instruction exp2/rcp form (absolute error ~1.5e-7) and parked in a per-wave LDS tile T[slot][check]; lanes 0..37 then
-//     turn their check's column into leave-one-out products with prefix/suffix products (31
-//     multiplies instead of 110) and each edge reads its own product back;
+//     a 5-instruction exp2/rcp form (absolute error ~1.5e-7) and parked in a per-wave, bit-major LDS tile with M0-relative
+//     add-TID stores; lanes 0..37 gather their check's eleven factors (one per round of an edge colouring, so no gather ever
+//     conflicts: ldpc_layout.h), form the leave-one-out products with prefix/suffix products (27 multiplies instead of 110)
+//     and store them check-major with add-TID stores; each edge reads its own product back.  34 LDS instructions per
+//     iteration: the CU's LDS pipe charges an instruction 2.3-4.3 cycles whatever its active lanes, and four SIMDs share it;
 //   * the piecewise-linear atanh keeps the reference's breakpoints and offsets; (z-c)/d is evaluated
-//     as (z-c)*(2/d), within 1 ulp of the reference's quotient;
+//     as z*(2/d) - c*(2/d) in one fma on the common piece, (z-c)*(2/d) on the rare upper pieces: within 1.6 ulp of the quotient;
 //   * CRC-13 runs as a wave-uniform bit-serial division only when all 38 checks are satisfied;
 //   * the 10th message update of the reference (whose result is never used) is skipped.
 // Work distribution: grid = (blocks per channel, channels); waves stride over the channel's index list
@@ -37,9 +39,8 @@ constexpr int kOneCell = kFwdCells;                // Tf[384] = 1.0
 constexpr int kBwdBase = kFwdCells + 8;            // Tb starts here (floats)
 constexpr int kTileFloats = kBwdBase + kMaxCheckDegree * kTStride;
 
-// Edge tables derived at compile time from the check-major graph and the lane layout of ldpc_layout.h (bit -> lane, check ->
-// lane and first-edge order were annealed offline so that the edge-side scatter/gather through the tile is at most 2-way
-// conflicted: 9 instead of 18 extra LDS cycles per iteration and direction; 2-way costs a ds_write_b32 nothing).
+// Edge tables derived at compile time from the check-major graph and the layout of ldpc_layout.h (bit -> lane, check -> lane,
+// first-edge order and the round in which a check lane meets each of its edges; tools/layout/make_layout.py).
 struct EdgeTables
 {
     uint16_t cell[2][64][kEdgesPerBit];  // backward-tile cell (relative to Tb) of the edge handled by instruction i of (half h, lane l)
