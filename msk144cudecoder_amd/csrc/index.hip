@@ -50,17 +50,27 @@ __global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st
     const int32_t* __restrict__ nbad = st.nbadsync + off;
     int32_t* __restrict__ out = st.idx + off;
     int base = 0;
-    for(int k0 = 0; k0 < st.K; k0 += kIdxThreads)
+    // The kernel is a chain of global-load latencies (one workgroup per channel, 24 steps for a deep window): fetch eight steps'
+    // worth of flags at once so that a latency is paid per 8192 items, not per 1024.
+    constexpr int kBatch = 8;
+    for(int k0 = 0; k0 < st.K; k0 += kBatch * kIdxThreads)
     {
-        const int k = k0 + threadIdx.x;
-        bool flag = false;
-        if(k < st.K)
+        int32_t nb[kBatch];
+#pragma unroll
+        for(int j = 0; j < kBatch; j++)
         {
-            flag = nbad[k] <= st.nbadsync_threshold;
-            st.dec_flag[off + k] = 0;  // clear_result (result_keeper.cuh:61-73) for the fields LDPC may set
+            const int k = k0 + j * kIdxThreads + threadIdx.x;
+            nb[j] = k < st.K ? nbad[k] : 0x7fffffff;
         }
-        const int slot = ordered_slot(flag, base, s_wave_count);
-        if(slot >= 0) out[slot] = k;
+#pragma unroll
+        for(int j = 0; j < kBatch; j++)
+        {
+            const int k = k0 + j * kIdxThreads + threadIdx.x;
+            if(k0 + j * kIdxThreads >= st.K) break;  // workgroup-uniform
+            if(k < st.K) st.dec_flag[off + k] = 0;  // clear_result (result_keeper.cuh:61-73) for the fields LDPC may set
+            const int slot = ordered_slot(nb[j] <= st.nbadsync_threshold, base, s_wave_count);
+            if(slot >= 0) out[slot] = k;
+        }
     }
     if(threadIdx.x == 0) st.n_idx[ch] = base;
 }
