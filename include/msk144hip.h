@@ -89,9 +89,11 @@ typedef struct msk144_params
                                    candidate's 128 softbits; ldpc_kernel.cuh:116-142 reads them back).  The LLR rows of a block
                                    (block x items x 512 B) are produced and consumed back to back, so the LLR store never grows
                                    with the batch (0.79 GB per 64-channel block at the deep config instead of 12.6 GB per 1024
-                                   channels).  0 = automatic: min(channels, 64) - measured +0.6 % step time at 64, +4 % at 16
-                                   (the per-block index launch).  Candidate dumps need every row retained:
-                                   = channels: retain everything (parity-dump mode) */
+                                   channels).  0 = automatic: min(channels, 64), the fastest setting measured (16: +5 %, 32: +1.5 %,
+                                   128: +1.5 %, 1024: +3 % step time).  With fewer channels per block than channels no row outlives
+                                   its block, and a candidate the nbadsync gate drops (index_kernel.cuh:7-76) is not demodulated
+                                   beyond its sync check.  Candidate dumps need every row retained:
+                                   = channels: retain everything, every candidate in full (parity-dump mode) */
 } msk144_params;
 
 /* One accepted decode (CRC ok, < 18 hard errors), fields as the reference's host loop consumes them

@@ -5,7 +5,12 @@
 // workgroup (8 waves) serves all D*8 candidates of a (channel, frequency) pair, mixes the window ONCE
 // into LDS (same float phase as the scan) and then each 64-lane wave demodulates candidates on its own,
 // entirely in registers - no workgroup barrier after the mix and no LDS scratch, so the only LDS is the
-// 41.5 KB window and three workgroups (24 waves) fit a CU.
+// 48.4 KB window (ring + one frame of pad) and three workgroups (24 waves) fit a CU.
+//
+// A candidate is demodulated in two parts: first the slots its sync check needs (slot 0 carries softbits 0..7 and 56..63,
+// slot 2 the partial sum that wraps into softbit 0), the carrier phase and nbadsync; then the middle slot, the
+// normalisation and the LLR row.  In blocked staging (no LLR row outlives its channel block) a candidate the index stage
+// will drop (nbadsync > threshold) stops after part one; with the LLR store retained every candidate is demodulated in full.
 //
 // Register layout: the 864-sample folded frame is cut into 144 half-bit groups of 6 samples; group
 // h = lane + 64*s (s = 0,1,2) lives in lane `lane`, slot `s`.  Softbit u needs groups u-1 and u
@@ -57,6 +62,125 @@ __device__ __forceinline__ float dpp_add(float v)
     return f32_add(v, dpp_f32<kCtrl>(v));
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
+typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
+
+// Fold of the averaged frames (softbits_kernel.cuh:59-82) for the slots named in kSlotMask.
+// A lane reads its group's six samples (48 B).  With ds_read_b64 the 48-byte lane stride makes lanes l and l + 16 of a
+// 32-lane access group share a bank pair (6*16 = 0 mod 32): a 2-way conflict on every read.  ds_read_b128 services 16 lanes
+// per cycle, and at this stride their sixteen 16-byte pieces tile all 64 banks exactly: conflict-free, 4 cycles per TWO
+// samples.  It needs 16-byte alignment, which depends only on the parity of the candidate position (wave-uniform; group
+// offsets 6g and frame offsets 864m are even): even -> three b128; odd -> b64, two b128, b64.  volatile keeps the compiler
+// from re-merging.  Frame 0 is part of every pattern (msk_context.cuh:231-238): its samples ARE the initial sums.
+template<int kSlotMask>
+__device__ __forceinline__ void fold_frames(v2f (&acc)[kSlots][kGroup], const char* xbytes, const uint32_t (&lane8)[kSlots], uint32_t pos, int p)
+{
+    const bool pos_even = (pos & 1u) == 0u;
+    if(pos_even)
+    {
+#pragma unroll
+        for(int s = 0; s < kSlots; s++)
+        {
+            if(!((kSlotMask >> s) & 1)) continue;
+            lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + (lane8[s] + pos * 8u));
+            const v4f q0 = q[0], q1 = q[1], q2 = q[2];
+            acc[s][0] = v2f{q0.x, q0.y};
+            acc[s][1] = v2f{q0.z, q0.w};
+            acc[s][2] = v2f{q1.x, q1.y};
+            acc[s][3] = v2f{q1.z, q1.w};
+            acc[s][4] = v2f{q2.x, q2.y};
+            acc[s][5] = v2f{q2.z, q2.w};
+        }
+        for(int m = 1; m < kPatternBits; m++)
+        {
+            if(!kPatternMask[p][m]) continue;  // wave-uniform
+            uint32_t fb = pos + static_cast<uint32_t>(kFrameSamples * m);  // frame base in the ring: scalar
+            if(fb >= static_cast<uint32_t>(kWindowSamples)) fb -= kWindowSamples;
+#pragma unroll
+            for(int s = 0; s < kSlots; s++)
+            {
+                if(!((kSlotMask >> s) & 1)) continue;
+                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + (lane8[s] + fb * 8u));
+                const v4f q0 = q[0], q1 = q[1], q2 = q[2];
+                acc[s][0] += v2f{q0.x, q0.y};
+                acc[s][1] += v2f{q0.z, q0.w};
+                acc[s][2] += v2f{q1.x, q1.y};
+                acc[s][3] += v2f{q1.z, q1.w};
+                acc[s][4] += v2f{q2.x, q2.y};
+                acc[s][5] += v2f{q2.z, q2.w};
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for(int s = 0; s < kSlots; s++)
+        {
+            if(!((kSlotMask >> s) & 1)) continue;
+            const uint32_t i8 = lane8[s] + pos * 8u;
+            lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
+            lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
+            acc[s][0] = r[0];
+            const v4f q0 = q[0], q1 = q[1];
+            acc[s][5] = r[5];
+            acc[s][1] = v2f{q0.x, q0.y};
+            acc[s][2] = v2f{q0.z, q0.w};
+            acc[s][3] = v2f{q1.x, q1.y};
+            acc[s][4] = v2f{q1.z, q1.w};
+        }
+        for(int m = 1; m < kPatternBits; m++)
+        {
+            if(!kPatternMask[p][m]) continue;  // wave-uniform
+            uint32_t fb = pos + static_cast<uint32_t>(kFrameSamples * m);
+            if(fb >= static_cast<uint32_t>(kWindowSamples)) fb -= kWindowSamples;
+#pragma unroll
+            for(int s = 0; s < kSlots; s++)
+            {
+                if(!((kSlotMask >> s) & 1)) continue;
+                const uint32_t i8 = lane8[s] + fb * 8u;
+                lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
+                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
+                const v2f x0 = r[0];
+                const v4f q0 = q[0], q1 = q[1];
+                const v2f x5 = r[5];
+                acc[s][0] += x0;
+                acc[s][1] += v2f{q0.x, q0.y};
+                acc[s][2] += v2f{q0.z, q0.w};
+                acc[s][3] += v2f{q1.x, q1.y};
+                acc[s][4] += v2f{q1.z, q1.w};
+                acc[s][5] += x5;
+            }
+        }
+    }
+}
+
+// Matched filter on the folded complex samples of one slot (softbits_kernel.cuh:157-180 before the rotation of :146-153).
+// The rotation is the same for every sample of the frame, so it commutes with the tap sums: filter the folded complex samples
+// first (two real FMAs per sample and pulse half) and rotate the two complex sums of a group afterwards - 28 instead of 36
+// multiply-adds per group.  Same linear form as rotating every sample first, associated differently (~1e-7 relative).
+// pp[0] = sin 0 = 0 and pp[6] = sin pi/2 = 1 exactly (checked at create): the first tap of u1 vanishes, u2's is the sample.
+__device__ __forceinline__ void filter_group(const v2f (&x)[kGroup], const float (&pp)[12], v2f& u1, v2f& u2)
+{
+    u1 = x[1] * pp[1];
+    u2 = x[0];
+#pragma unroll
+    for(int t = 1; t < kGroup; t++)
+    {
+        if(t > 1)
+        {
+            u1.x = fmaf(x[t].x, pp[t], u1.x);
+            u1.y = fmaf(x[t].y, pp[t], u1.y);
+        }
+        u2.x = fmaf(x[t].x, pp[kGroup + t], u2.x);
+        u2.y = fmaf(x[t].y, pp[kGroup + t], u2.y);
+    }
+}
+
+// kGateEarly: blocked staging keeps no LLR row of a candidate the index stage will drop (nbadsync > threshold), so such a
+// candidate stops after its sync check - a third of the noise candidates at threshold 3.  With the LLR store retained
+// (llr_block_channels = channels: dumps, parity tests) every candidate is demodulated in full, as in the reference.
+template<bool kGateEarly>
 __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsArgs a)
 {
     __shared__ __attribute__((aligned(16))) float2 s_x[kWindowSamples + kRingPad + 3];
@@ -167,118 +291,15 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), i));
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
 
-        // ---- fold the averaged frames (softbits_kernel.cuh:59-82) ----
+        // ---- part 1: everything the sync check needs.  The sync softbits 0..7 and 56..63 live in slot 0; softbit 0 also takes
+        // the partial sum that starts in group 143 (slot 2, lane 15): the frame is circular.  Slot 1 waits. ----
         v2f acc[kSlots][kGroup];  // (re, im) pairs
-        // A lane reads its group's six samples (48 B).  With ds_read_b64 the 48-byte lane stride makes lanes l and l + 16 of a
-        // 32-lane access group share a bank pair (6*16 = 0 mod 32): a 2-way conflict on every read, 4 LDS cycles per sample
-        // pair and the largest single cost of this kernel.  ds_read_b128 services 16 lanes per cycle, and at this stride their
-        // sixteen 16-byte pieces tile all 64 banks exactly: conflict-free, 4 cycles per TWO samples.  It needs 16-byte
-        // alignment, which depends only on the parity of the candidate position (wave-uniform; group offsets 6g and frame
-        // offsets 864m are even): even -> three b128; odd -> b64, two b128, b64.  volatile keeps the compiler from re-merging.
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
-        typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
-        const bool pos_even = (pos & 1u) == 0u;
-        // frame 0 is part of every pattern (msk_context.cuh:231-238): its samples ARE the initial sums (no add to zero)
-        if(pos_even)
-        {
-#pragma unroll
-            for(int s = 0; s < kSlots; s++)
-            {
-                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + (lane8[s] + pos * 8u));
-                const v4f q0 = q[0], q1 = q[1], q2 = q[2];
-                acc[s][0] = v2f{q0.x, q0.y};
-                acc[s][1] = v2f{q0.z, q0.w};
-                acc[s][2] = v2f{q1.x, q1.y};
-                acc[s][3] = v2f{q1.z, q1.w};
-                acc[s][4] = v2f{q2.x, q2.y};
-                acc[s][5] = v2f{q2.z, q2.w};
-            }
-            for(int m = 1; m < kPatternBits; m++)
-            {
-                if(!kPatternMask[p][m]) continue;  // wave-uniform
-                uint32_t fb = pos + static_cast<uint32_t>(kFrameSamples * m);  // frame base in the ring: scalar
-                if(fb >= static_cast<uint32_t>(kWindowSamples)) fb -= kWindowSamples;
-#pragma unroll
-                for(int s = 0; s < kSlots; s++)
-                {
-                    lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + (lane8[s] + fb * 8u));
-                    const v4f q0 = q[0], q1 = q[1], q2 = q[2];
-                    acc[s][0] += v2f{q0.x, q0.y};
-                    acc[s][1] += v2f{q0.z, q0.w};
-                    acc[s][2] += v2f{q1.x, q1.y};
-                    acc[s][3] += v2f{q1.z, q1.w};
-                    acc[s][4] += v2f{q2.x, q2.y};
-                    acc[s][5] += v2f{q2.z, q2.w};
-                }
-            }
-        }
-        else
-        {
-#pragma unroll
-            for(int s = 0; s < kSlots; s++)
-            {
-                const uint32_t i8 = lane8[s] + pos * 8u;
-                lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
-                lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
-                acc[s][0] = r[0];
-                const v4f q0 = q[0], q1 = q[1];
-                acc[s][5] = r[5];
-                acc[s][1] = v2f{q0.x, q0.y};
-                acc[s][2] = v2f{q0.z, q0.w};
-                acc[s][3] = v2f{q1.x, q1.y};
-                acc[s][4] = v2f{q1.z, q1.w};
-            }
-            for(int m = 1; m < kPatternBits; m++)
-            {
-                if(!kPatternMask[p][m]) continue;  // wave-uniform
-                uint32_t fb = pos + static_cast<uint32_t>(kFrameSamples * m);
-                if(fb >= static_cast<uint32_t>(kWindowSamples)) fb -= kWindowSamples;
-#pragma unroll
-                for(int s = 0; s < kSlots; s++)
-                {
-                    const uint32_t i8 = lane8[s] + fb * 8u;
-                    lds_v2f_ptr r = (lds_v2f_ptr)(xbytes + i8);
-                    lds_v4f_ptr q = (lds_v4f_ptr)(xbytes + i8 + 8);
-                    const v2f x0 = r[0];
-                    const v4f q0 = q[0], q1 = q[1];
-                    const v2f x5 = r[5];
-                    acc[s][0] += x0;
-                    acc[s][1] += v2f{q0.x, q0.y};
-                    acc[s][2] += v2f{q0.z, q0.w};
-                    acc[s][3] += v2f{q1.x, q1.y};
-                    acc[s][4] += v2f{q1.z, q1.w};
-                    acc[s][5] += x5;
-                }
-            }
-        }
-
-        // ---- matched filter on the folded complex samples (softbits_kernel.cuh:157-180 before the rotation of :146-153) ----
-        // The rotation is the same for every sample of the frame, so it commutes with the tap sums: filter the folded complex
-        // samples first (two real FMAs per sample and pulse half) and rotate the two complex sums of a group afterwards - 28
-        // instead of 36 multiply-adds per group.  Same linear form as rotating every sample first, associated differently
-        // (~1e-7 relative).  The folded samples are dead after this loop.
         v2f u1[kSlots], u2[kSlots];
-#pragma unroll
-        for(int s = 0; s < kSlots; s++)
-        {
-            // pp[0] = sin 0 = 0 and pp[6] = sin pi/2 = 1 exactly (checked at create): the first tap of u1 vanishes, u2's is the sample
-            u1[s] = acc[s][1] * pp[1];
-            u2[s] = acc[s][0];
-#pragma unroll
-            for(int t = 1; t < kGroup; t++)
-            {
-                if(t > 1)
-                {
-                    u1[s].x = fmaf(acc[s][t].x, pp[t], u1[s].x);
-                    u1[s].y = fmaf(acc[s][t].y, pp[t], u1[s].y);
-                }
-                u2[s].x = fmaf(acc[s][t].x, pp[kGroup + t], u2[s].x);
-                u2[s].y = fmaf(acc[s][t].y, pp[kGroup + t], u2[s].y);
-            }
-        }
+        fold_frames<0b101>(acc, xbytes, lane8, pos, p);
+        filter_group(acc[0], pp, u1[0], u2[0]);
+        filter_group(acc[2], pp, u1[2], u2[2]);
 
-        // ---- carrier phase from the two sync words (softbits_kernel.cuh:88-137): sum c3[k]*conj(cb[k]) ----
+        // carrier phase from the two sync words (softbits_kernel.cuh:88-137): sum c3[k]*conj(cb[k])
         float pr = fmaf(k_u2y, u2[0].y, fmaf(k_u1y, u1[0].y, fmaf(k_u2x, u2[0].x, k_u1x * u1[0].x)));
         float pi = fmaf(-k_u2y, u2[0].x, fmaf(-k_u1y, u1[0].x, fmaf(k_u2x, u2[0].y, k_u1x * u1[0].y)));
         wave_sum2_f32(pr, pi);
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             }
         }
 
-        // ---- de-rotate the filtered sums (softbits_kernel.cuh:146-153) ----
+        // de-rotate the filtered sums (softbits_kernel.cuh:146-153)
         // va = plane that STARTS a softbit in this lane (even group -> I bit u+1 -> real part,
         // odd group -> Q bit u+1 -> imaginary part); vb = plane that FINISHES softbit u = this group.
         // re = fr*cr - fi*ci, im = fr*ci + fi*cr: pick the coefficient pair per lane once instead of
@@ -308,16 +329,34 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const float a_r = odd ? ci : cr, a_i = odd ? cr : -ci;   // va = fr*a_r + fi*a_i
         const float b_r = odd ? cr : ci, b_i = odd ? -ci : cr;   // vb = fr*b_r + fi*b_i
         float start[kSlots], soft[kSlots];
-#pragma unroll
-        for(int s = 0; s < kSlots; s++) start[s] = fmaf(u1[s].y, a_i, u1[s].x * a_r);
-#pragma unroll
-        for(int s = 0; s < kSlots; s++)
+        start[0] = fmaf(u1[0].y, a_i, u1[0].x * a_r);
+        start[2] = fmaf(u1[2].y, a_i, u1[2].x * a_r);
         {
-            // incoming partial sum from group h-1: lane-1 of the same slot; lane 0 takes lane 63 of the
-            // previous slot, and group 0 takes group 143 (slot 2, lane 15): the frame is circular
-            float in = dpp_f32<kDppWaveShr1>(start[s]);
-            const float edge = (s == 0) ? readlane_f32(start[kSlots - 1], kGroups - 64 * (kSlots - 1) - 1) : readlane_f32(start[s - 1], 63);
+            // incoming partial sum from group h-1: lane-1 of the same slot; group 0 takes group 143 (slot 2, lane 15)
+            float in = dpp_f32<kDppWaveShr1>(start[0]);
+            const float edge = readlane_f32(start[kSlots - 1], kGroups - 64 * (kSlots - 1) - 1);
             asm("v_writelane_b32 %0, %1, 0" : "+v"(in) : "s"(edge));  // lane 0 <- edge (one instruction instead of v_mov + v_cndmask)
+            soft[0] = in + fmaf(u2[0].y, b_i, u2[0].x * b_r);
+        }
+
+        // ---- sync-word disagreements (softbits_kernel.cuh:214-241): bits 0..7 and 56..63 ----
+        const int hard = (soft[0] < 0.0f) ? -1 : 1;
+        const bool disagree = sync_pm != 0 && hard != sync_pm;
+        const int nbad = __popcll(__ballot(disagree));
+        if(lane == 0) a.st.nbadsync[item] = nbad;
+        if(kGateEarly && nbad > a.st.nbadsync_threshold) continue;  // wave-uniform: the index stage drops this candidate
+
+        // ---- part 2: the middle slot and the rest of the demodulation ----
+        fold_frames<0b010>(acc, xbytes, lane8, pos, p);
+        filter_group(acc[1], pp, u1[1], u2[1]);
+        start[1] = fmaf(u1[1].y, a_i, u1[1].x * a_r);
+#pragma unroll
+        for(int s = 1; s < kSlots; s++)
+        {
+            // lane 0 takes lane 63 of the previous slot
+            float in = dpp_f32<kDppWaveShr1>(start[s]);
+            const float edge = readlane_f32(start[s - 1], 63);
+            asm("v_writelane_b32 %0, %1, 0" : "+v"(in) : "s"(edge));
             const float sb = in + fmaf(u2[s].y, b_i, u2[s].x * b_r);
             soft[s] = (s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) ? 0.0f : sb;
         }
@@ -346,17 +385,11 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const float sigma = 0.60f;
         const float scale = 2.0f * __builtin_amdgcn_rcpf(ssig * (sigma * sigma));
 
-        // ---- sync-word disagreements (softbits_kernel.cuh:214-241): bits 0..7 and 56..63 ----
-        const int hard = (soft[0] < 0.0f) ? -1 : 1;
-        const bool disagree = sync_pm != 0 && hard != sync_pm;
-        const int nbad = __popcll(__ballot(disagree));
-
         // ---- store (softbits_kernel.cuh:204-211,244-247) ----
         float* __restrict__ llr = a.st.llr + (item - static_cast<size_t>(a.st.ch0) * a.st.K) * kCodeBits;
         if(lane >= 8 && lane < 56) llr[lane - 8] = f32_mul(scale, soft[0]);      // u = 8..55    -> 0..47
         llr[48 + lane] = f32_mul(scale, soft[1]);                                // u = 64..127  -> 48..111
         if(lane < 16) llr[112 + lane] = f32_mul(scale, soft[2]);                 // u = 128..143 -> 112..127
-        if(lane == 0) a.st.nbadsync[item] = nbad;
     }
 }
 
@@ -370,7 +403,9 @@ void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t
     a.total_tiles = st.nch * st.F;
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
     const int grid = a.tiles_per_xcd * 8;
-    hipLaunchKernelGGL(softbits_kernel, dim3(grid), dim3(kSbThreads), 0, stream, a);
+    // LLR rows are retained only when one block covers every channel (msk144_api.cpp: dumps, parity tests)
+    if(st.nch < st.channels) hipLaunchKernelGGL(softbits_kernel<true>, dim3(grid), dim3(kSbThreads), 0, stream, a);
+    else hipLaunchKernelGGL(softbits_kernel<false>, dim3(grid), dim3(kSbThreads), 0, stream, a);
 }
 
 }  // namespace msk144
