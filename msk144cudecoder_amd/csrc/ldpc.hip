@@ -270,10 +270,19 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             const uint64_t hi = __ballot(cw[1]);
 
             // 38 parity checks: lane c < 38 evaluates check c
-            // parity of popcount(cw & H_row): fold the four masked dwords with XOR first (full-rate ops) and count once
-            // (v_bcnt is half rate): 9 instead of 13 instructions
-            const uint64_t masked = (lo & hlo) ^ (hi & hhi);
-            const int par = __popc(static_cast<uint32_t>(masked) ^ static_cast<uint32_t>(masked >> 32)) & 1;
+            // parity of popcount(cw & H_row): fold the four masked dwords with XOR first and count once (v_bcnt is half rate)
+            // v_bitop3_b32 with truth table 0x6a is (a & b) ^ c: one instruction per masked dword after the first
+            uint32_t folded = static_cast<uint32_t>(lo) & static_cast<uint32_t>(hlo);
+            // gfx940-family hazard: a VALU may read an SGPR written by a VALU (the ballots' v_cmp) only two wait states later;
+            // the compiler pads its own instructions, an asm statement has to carry its own s_nop
+            asm("s_nop 1\n\t"
+                "v_bitop3_b32 %0, %1, %4, %0 bitop3:0x6a\n\t"
+                "v_bitop3_b32 %0, %2, %5, %0 bitop3:0x6a\n\t"
+                "v_bitop3_b32 %0, %3, %6, %0 bitop3:0x6a"
+                : "+v"(folded)
+                : "s"(static_cast<uint32_t>(lo >> 32)), "s"(static_cast<uint32_t>(hi)), "s"(static_cast<uint32_t>(hi >> 32)),
+                  "v"(static_cast<uint32_t>(hlo >> 32)), "v"(static_cast<uint32_t>(hhi)), "v"(static_cast<uint32_t>(hhi >> 32)));
+            const int par = __popc(folded) & 1;
             const uint64_t syndrome = __ballot(par != 0) & ((1ull << kChecks) - 1ull);
 
             if(syndrome == 0)

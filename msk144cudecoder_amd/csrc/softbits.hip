@@ -335,7 +335,9 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             // incoming partial sum from group h-1: lane-1 of the same slot; group 0 takes group 143 (slot 2, lane 15)
             float in = dpp_f32<kDppWaveShr1>(start[0]);
             const float edge = readlane_f32(start[kSlots - 1], kGroups - 64 * (kSlots - 1) - 1);
-            asm("v_writelane_b32 %0, %1, 0" : "+v"(in) : "s"(edge));  // lane 0 <- edge (one instruction instead of v_mov + v_cndmask)
+            // lane 0 <- edge (one instruction instead of v_mov + v_cndmask).  `edge` comes out of a v_readlane: on the gfx940 family a
+            // VALU may read an SGPR written by a VALU only two wait states later, and the compiler does not pad asm statements
+            asm("s_nop 1\n\tv_writelane_b32 %0, %1, 0" : "+v"(in) : "s"(edge));
             soft[0] = in + fmaf(u2[0].y, b_i, u2[0].x * b_r);
         }
 
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             // lane 0 takes lane 63 of the previous slot
             float in = dpp_f32<kDppWaveShr1>(start[s]);
             const float edge = readlane_f32(start[s - 1], 63);
-            asm("v_writelane_b32 %0, %1, 0" : "+v"(in) : "s"(edge));
+            asm("s_nop 1\n\tv_writelane_b32 %0, %1, 0" : "+v"(in) : "s"(edge));
             const float sb = in + fmaf(u2[s].y, b_i, u2[s].x * b_r);
             soft[s] = (s == kSlots - 1 && lane >= kGroups - 64 * (kSlots - 1)) ? 0.0f : sb;
         }

@@ -3,6 +3,9 @@
 wave64.h carries hand-counted wait states inside inline-asm strings (hipcc inserts no hazard nops for asm statements):
   * a DPP instruction needs >= 2 wait states after a VALU write of a VGPR it reads;
   * a DPP instruction needs >= 5 wait states after a VALU write of EXEC (v_cmpx*);
+  * on the gfx940 family (gfx950 included) a VALU instruction may read an SGPR written by a VALU instruction (v_cmp, v_readlane,
+    v_readfirstlane) only two wait states later.  The compiler pads its own instructions; every VALU instruction INSIDE one of our
+    asm statements is checked here (softbits.hip: v_writelane of a v_readlane result; ldpc.hip: v_bitop3 of the ballot words);
   * an LDS add-TID instruction (ds_write_addtid_b32 / ds_read_addtid_b32, ldpc.hip) needs >= 1 wait state after an SALU write of M0
     (skipping it sent one column store per wave through a stale M0: a BP iteration count off by one in 1 of 22 000 codewords).
 This test compiles every kernel source with the build's own flags, walks each straight-line stretch of the listing and
@@ -19,6 +22,21 @@ import pytest
 from msk144cudecoder_amd import build as B
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]|\b(vcc_lo|vcc_hi|vcc)\b")
+
+
+def _sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None:
+            out.add("s" + m.group(1))
+        elif m.group(2) is not None:
+            out.update("s%d" % i for i in range(int(m.group(2)), int(m.group(3)) + 1))
+        elif m.group(4) == "vcc":
+            out.update(("vcc_lo", "vcc_hi"))
+        else:
+            out.add(m.group(4))
+    return out
 
 
 def _regs(text):
@@ -42,19 +60,39 @@ def _listing(src, extra):
 def check_listing(lines):
     """Returns (number of DPP instructions checked, list of violations)."""
     window = []      # straight-line history: (mnemonic, written vgprs, is_exec_write, wait_states_it_provides)
+    swindow = []     # same stretch: (mnemonic, SGPRs written by a VALU instruction, wait_states_it_provides)
+    in_asm = False
     checked, bad = 0, []
     for ln, raw in enumerate(lines, 1):
+        if "#ASMSTART" in raw:
+            in_asm = True
+        elif "#ASMEND" in raw:
+            in_asm = False
         line = raw.split(";")[0].strip()
         if not line or line.startswith((".", "//")):
             continue
         if line.endswith(":"):
             window = []
+            swindow = []
             continue
         parts = line.split(None, 1)
         op, args = parts[0], (parts[1] if len(parts) > 1 else "")
         if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
             window = []
+            swindow = []
             continue
+        if in_asm and op.startswith("v_"):
+            operands = [a.strip() for a in args.split(",")]
+            reads = _sregs(",".join(operands[1:])) if not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) else _sregs(",".join(operands[1:]))
+            if reads:
+                checked += 1
+                states = 0
+                for mn, swritten, provides in reversed(swindow):
+                    if swritten & reads and states < 2:
+                        bad.append((ln, raw.strip(), f"only {states} wait states after {mn} writes {sorted(swritten & reads)} (VALU -> SGPR -> VALU), need 2"))
+                    states += provides
+                    if states >= 2:
+                        break
         if "_addtid_" in op:
             checked += 1
             states = 0
@@ -91,6 +129,14 @@ def check_listing(lines):
         window.append((op, written, exec_write, provides))
         if len(window) > 16:
             window.pop(0)
+        swritten = set()
+        if op.startswith(("v_readlane", "v_readfirstlane")):
+            swritten = _sregs(args.split(",")[0])
+        elif op.startswith("v_cmp"):
+            swritten = _sregs(args.split(",")[0]) if op.endswith("_e64") or "_e64" in op else {"vcc_lo", "vcc_hi"}
+        swindow.append((op, swritten, provides))
+        if len(swindow) > 8:
+            swindow.pop(0)
     return checked, bad
 
 
@@ -102,6 +148,10 @@ def test_checker_catches_a_planted_hazard():
     n, bad = check_listing(["\tv_cmpx_gt_f32_e32 v1, v2", "\ts_nop 3", "\tv_max_f32_dpp v4, v5, v5 row_mirror row_mask:0xf bank_mask:0xf"])
     assert len(bad) == 1 and "EXEC" in bad[0][2]
     assert check_listing(["\tv_cmpx_gt_f32_e32 v1, v2", "\ts_nop 4", "\tv_max_f32_dpp v4, v5, v5 row_mirror row_mask:0xf bank_mask:0xf"])[1] == []
+    n, bad = check_listing(["\tv_readlane_b32 s1, v10, 15", "\t;;#ASMSTART", "\tv_writelane_b32 v2, s1, 0", "\t;;#ASMEND"])
+    assert len(bad) == 1 and "VALU -> SGPR -> VALU" in bad[0][2]
+    assert check_listing(["\tv_readlane_b32 s1, v10, 15", "\t;;#ASMSTART", "\ts_nop 1", "\tv_writelane_b32 v2, s1, 0", "\t;;#ASMEND"])[1] == []
+    assert check_listing(["\tv_cmp_lt_f32_e64 s[0:1], 0, v47", "\t;;#ASMSTART", "\ts_nop 0", "\tv_bitop3_b32 v49, s1, v9, v49 bitop3:0x6a", "\t;;#ASMEND"])[1] != []
     n, bad = check_listing(["\ts_mov_b32 m0, s4", "\tds_write_addtid_b32 v1 offset:0"])
     assert n == 1 and len(bad) == 1 and "M0" in bad[0][2]
     assert check_listing(["\ts_mov_b32 m0, s4", "\ts_nop 0", "\tds_write_addtid_b32 v1 offset:0", "\tds_read_addtid_b32 v2 offset:4"]) == (2, [])
