@@ -408,9 +408,11 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 
 void launch_ldpc(const DeviceStore& st, hipStream_t stream)
 {
-    // enough waves to fill 256 CUs x 8 waves/SIMD x 4 SIMDs even for one channel
+    // Sixteen times the 2048 workgroups the chip holds at once: codewords need 1 to 10 iterations, and with a static stride the
+    // only load balancing is the dispatcher handing out fresh workgroups - 32768 workgroups (about eight codewords per wave
+    // at the bench workload) measured 2.5 % faster than 8192 and 13 % faster than one resident set (2048).
     const int max_waves_per_channel = (st.K + kLdpcWaves - 1) / kLdpcWaves;
-    int blocks = (8192 + st.nch - 1) / st.nch;
+    int blocks = (32768 + st.nch - 1) / st.nch;
     if(blocks > max_waves_per_channel) blocks = max_waves_per_channel;
     if(blocks < 1) blocks = 1;
     hipLaunchKernelGGL(ldpc_kernel, dim3(blocks, st.nch), dim3(kLdpcThreads), 0, stream, st);
