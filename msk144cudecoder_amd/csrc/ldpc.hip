@@ -29,7 +29,7 @@ namespace msk144
 namespace
 {
 
-constexpr int kLdpcThreads = 256;
+constexpr int kLdpcThreads = 64;   // one wave per workgroup: waves never wait for a slower sibling to free the workgroup's slot (-1.5 % against 256)
 constexpr int kLdpcWaves = kLdpcThreads / 64;
 constexpr int kTStride = kTileRowStride;  // backward tile Tb[round][lane of check] row stride (ldpc_layout.h)
 // Per-wave LDS: forward tile Tf[3h + i][lane] (bit-major: the tanh of the edge instruction i of half h handles in lane l), one
@@ -408,11 +408,12 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 
 void launch_ldpc(const DeviceStore& st, hipStream_t stream)
 {
-    // Sixteen times the 2048 workgroups the chip holds at once: codewords need 1 to 10 iterations, and with a static stride the
-    // only load balancing is the dispatcher handing out fresh workgroups - 32768 workgroups (about eight codewords per wave
-    // at the bench workload) measured 2.5 % faster than 8192 and 13 % faster than one resident set (2048).
+    // Sixteen times the 8192 waves the chip holds at once: codewords need 1 to 10 iterations, and with a static stride the only
+    // load balancing is the dispatcher handing out fresh workgroups - 131072 waves per launch (about eight codewords per wave
+    // at the bench workload) measured 2.5 % faster than 32768 and 13 % faster than one resident set (8192).
+    constexpr int kWavesPerLaunch = 131072;
     const int max_waves_per_channel = (st.K + kLdpcWaves - 1) / kLdpcWaves;
-    int blocks = (32768 + st.nch - 1) / st.nch;
+    int blocks = (kWavesPerLaunch / kLdpcWaves + st.nch - 1) / st.nch;
     if(blocks > max_waves_per_channel) blocks = max_waves_per_channel;
     if(blocks < 1) blocks = 1;
     hipLaunchKernelGGL(ldpc_kernel, dim3(blocks, st.nch), dim3(kLdpcThreads), 0, stream, st);
