@@ -67,7 +67,18 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+_INPUTS = {}
+
+
 def make_inputs(rank: int, channels: int):
+    """Cached per (rank, channels): the CPU baseline and the GPU backend of one process see the same arrays."""
+    key = (rank, channels)
+    if key not in _INPUTS:
+        _INPUTS[key] = _make_inputs(rank, channels)
+    return _INPUTS[key]
+
+
+def _make_inputs(rank: int, channels: int):
     """[T][channels][5184] int16: AWGN sigma=1000 LSB, every 4th channel carries one 0 dB ping
     (S2-style) somewhere in its 1.08 s of signal.  Returns (windows, {channel: msg})."""
     from msk144cudecoder_amd import synth
@@ -148,11 +159,36 @@ class HipBackend:
         self.dec.close()
 
 
+def usable_cores() -> int:
+    """Every host core this process may run on: the scheduler affinity mask, cut to the cgroup CPU quota when one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            w = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if w[0] != "max":
+                    n = min(n, max(1, int(int(w[0]) / int(w[1]) + 0.5)))
+            else:
+                q = int(w[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(windows: np.ndarray, budget_s: float = 12.0):
-    """Oracle ('port' of the reference algorithm) on the host cores, bounded sample of the same workload."""
+    """Oracle ('port' of the reference algorithm) on ALL usable host cores, bounded sample of the same workload.  Timed on its
+    own build of the oracle source (-O3 -march=native, compiled on this host: oracle.build_bench_library); the parity tests keep
+    the -O2 build."""
     from oracle import oracle as orc  # test infrastructure: used here only as the timed CPU baseline
-    cores = min(os.cpu_count() or 1, 16)
-    o = orc.Oracle(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, threads=cores)
+    cores = usable_cores()
+    o = orc.Oracle(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, threads=cores, library=orc.bench_lib())
     done = 0
     t0 = time.perf_counter()
     while True:
@@ -163,8 +199,26 @@ def cpu_baseline(windows: np.ndarray, budget_s: float = 12.0):
         el = time.perf_counter() - t0
         if el + el / done > budget_s or done >= 64:
             break
-    return {"value": done * o.total_items / el, "unit": "candidates/s", "cores": cores, "kind": "port",
+    return {"value": done * o.total_items / el, "unit": "candidates/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+            "flags": " ".join(orc.BENCH_FLAGS) + "; OpenMP over frequency hypotheses (scan, softbits) and gated candidates (BP)",
             "sample": f"{done} window(s) of channel(s) 0..{done - 1}, step 0 (of {windows.shape[1]} channels), {el:.1f} s; exhaustive reference algorithm, not WSJT-X msk144spd"}
+
+
+def roofline_valu(valu, lds, dom):
+    """The roofline that binds: VALU issue (wave64 instructions per second per SIMD) and, for LDPC, the CU's LDS pipe.  `nominal`
+    prices every VALU instruction at the guide's 2 cycles; `priced` uses the per-class issue costs measured by
+    tools/ubench/valu_rates.hip (profiles/r02_valu_issue_microbench.txt: min/max/compare/select/DPP 4.3 cycles, exp/rcp/sqrt 8.2)
+    and is empirical.  None when the static counters are stale for these kernel sources."""
+    if not valu or (dom + "_kernel") not in valu:
+        return None
+    k = dom + "_kernel"
+    out = {"bound": "valu-issue", "kernel": k, "unit": "wave64 VALU instr/s", "achieved": valu[k]["achieved"], "peak": valu["peak"],
+           "frac_nominal": valu[k]["frac"], "frac_priced": valu[k].get("frac_priced"),
+           "priced_note": valu.get("priced_note"), "static": valu.get("static")}
+    if lds and k in lds:
+        out["lds_pipe_busy"] = lds[k]["frac"]
+        out["lds_conflict_share"] = lds[k]["conflict_share"]
+    return out
 
 
 def parse_args(argv=None):
@@ -230,6 +284,16 @@ def run_worker(args) -> int:
         return 2
 
     Backend = importlib.import_module(args.backend_module).Backend if args.backend_module else HipBackend
+    channels = args.channels
+
+    # The CPU baseline runs FIRST, on rank 0, before anything touches the GPU: the GPU phase is then the tail of the process
+    # (a sampler of GPU activity catches it), and the other ranks of a distributed run simply wait for rank 0 at the rendezvous.
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and Backend is HipBackend:
+        cpu = cpu_baseline(make_inputs(0, channels)[0])
+        if distributed and world > 1:
+            cpu["sample"] += f"; timed while the other {world - 1} rank(s) of the job were starting up on the same host"
+
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -239,7 +303,6 @@ def run_worker(args) -> int:
         else:
             dist.init_process_group(Backend.dist_backend)
 
-    channels = args.channels
     channel_base, _ = sharding.shard_channels(channels * world, rank, world)   # rank r owns global channels [r*C, (r+1)*C)
     be = Backend(rank, local_rank, channels, channel_base, args.llr_block)
     cand_per_step = be.cand_per_step
@@ -249,11 +312,13 @@ def run_worker(args) -> int:
         cap = sharding.gather_capacity(channels)
         gather = sharding.RecordGather(cap, be.device, world, rank)
 
+    timing = {"on": False}
+
     def step(i):
         be.step(i)
         if gather is not None:
             # the path's only exchange: fixed-size decoded-record buffers -> rank 0 (RCCL over xGMI)
-            gather.step(be.rec_view, be.cnt_view)
+            gather.step(be.rec_view, be.cnt_view, timed=timing["on"])
 
     def fence():
         if distributed:
@@ -264,6 +329,7 @@ def run_worker(args) -> int:
         step(i)
     fence()
     be.start_profiling()
+    timing["on"] = True
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -271,10 +337,13 @@ def run_worker(args) -> int:
     fence()
     elapsed = time.perf_counter() - t0
 
+    rank_ms = [elapsed / args.steps * 1e3]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=be.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        elapsed = max(float(x.item()) for x in every)            # MAX over ranks
 
     stage = be.stage_times()
     last = be.results()
@@ -349,23 +418,31 @@ def run_worker(args) -> int:
             "config": {"workload": f"BASELINE configs[2]: {channels} synthetic 12 ksps int16 audio channels per GPU, one 5184-sample window per "
                                    f"channel per step, width=500 step=1 depth=6 nbadsync-threshold=3 (F={be.F}, D={be.D}, {be.K} candidates/window)",
                        "channels_per_gpu": channels, "candidates_per_step_per_gpu": cand_per_step, "parallelism": f"channel-shard x{world}",
-                       "analytic_method": 2, "llr_block_channels": getattr(be, "llr_block", None), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
+                       "analytic_method": 2, "llr_block_channels": getattr(be, "llr_block", None),
+                       "llr_store": f"blocked/{llr_block}" if llr_block < channels else "retained",
+                       "softbits_gate_early": bool(llr_block < channels), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
                        "real_time_channels": value / be.K / (12000.0 / 2592.0)},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_launch, "avg_launch_ms": dom_ms, "launches_per_step": launches,
                          "candidates_per_launch": cand_per_launch,
-                         "note": "path is VALU/LDS-bound (SURVEY.md 8d); HBM fraction reported as measured"},
+                         "mode": ("blocked staging: LLR rows are written only for candidates that pass the nbadsync gate and live for one "
+                                  f"{llr_block}-channel block; a gated-out candidate stops after its sync check (softbits_kernel<true>)")
+                                 if llr_block < channels else "retained: every candidate demodulated in full, every LLR row kept (parity-dump mode)",
+                         "note": "the contract's HBM figure; the path is VALU-issue/LDS-pipe bound (SURVEY.md 8d) - the binding roofline is roofline_valu"},
+            "roofline_valu": roofline_valu(valu, lds, dom),
             "valu_issue": valu,
             "lds_array": lds,
             "stage_ms": {n: round(stage[n][0], 4) for n in T_NAMES},
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": [round(x, 4) for x in rank_ms]},
             "decodes_last_step": int(len(last)), "channels_decoded_last_step": chans_decoded, "crc13_false_positives_last_step": wrong,
         }
         if gather is not None:
             out["gather"] = {"records_last_step": gathered_records, "capacity_per_rank": gather.cap, "bytes_per_rank": int(gather.send.numel()),
-                             "peak_records_per_rank": [int(x) for x in gather.max_total.cpu().numpy()], "backend": Backend.dist_backend}
-        if not distributed and not args.no_cpu_baseline and Backend is HipBackend:
-            out["cpu_baseline"] = cpu_baseline(be.wins_host)
+                             "peak_records_per_rank": [int(x) for x in gather.max_total.cpu().numpy()], "backend": Backend.dist_backend,
+                             "ms_per_step": gather.mean_ms(), "ms_note": "copy into the send buffer + gather, timed on rank 0 around RecordGather.step"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
     be.close()

@@ -31,20 +31,19 @@ namespace
 
 constexpr int kLdpcThreads = 64;   // one wave per workgroup: waves never wait for a slower sibling to free the workgroup's slot (-1.5 % against 256)
 constexpr int kLdpcWaves = kLdpcThreads / 64;
-constexpr int kTStride = kTileRowStride;  // backward tile Tb[round][lane of check] row stride (ldpc_layout.h)
-// Per-wave LDS: forward tile Tf[3h + i][lane] (bit-major: the tanh of the edge instruction i of half h handles in lane l), one
-// cell holding the constant 1.0 (the missing eleventh factor of the degree-10 checks), then the backward tile Tb.
+// Per-wave LDS (ldpc_layout.h): forward tile Tf[3h + i][lane] (bit-major: the tanh of the edge instruction i of half h handles in
+// lane l), 32 cells holding the constant 1.0, one per bank (the missing eleventh factor of the degree-10 checks, read from a bank
+// the real reads of the same access leave free), then the eleven backward rows Tb[round] at kRowBase[round] + lane of the check.
 constexpr int kFwdCells = 2 * kEdgesPerBit * 64;   // 384
-constexpr int kOneCell = kFwdCells;                // Tf[384] = 1.0
-constexpr int kBwdBase = kFwdCells + 8;            // Tb starts here (floats)
-constexpr int kTileFloats = kBwdBase + kMaxCheckDegree * kTStride;
+static_assert(kOnesBase == kFwdCells && kOnesBase % 32 == 0, "cell kOnesBase + b sits on bank b, right behind the forward tile");
+constexpr int kTileFloats = kTileCells;
 
 // Edge tables derived at compile time from the check-major graph and the layout of ldpc_layout.h (bit -> lane, check -> lane,
 // first-edge order and the round in which a check lane meets each of its edges; tools/layout/make_layout.py).
 struct EdgeTables
 {
-    uint16_t cell[2][64][kEdgesPerBit];  // backward-tile cell (relative to Tb) of the edge handled by instruction i of (half h, lane l)
-    uint16_t fwd[64][kMaxCheckDegree];   // forward-tile cell check lane L reads in round r (kOneCell where the check has no edge)
+    uint16_t cell[2][64][kEdgesPerBit];  // backward cell (tile-relative) of the edge handled by instruction i of (half h, lane l)
+    uint16_t fwd[64][kMaxCheckDegree];   // forward-tile cell check lane L reads in round r (a 1.0 cell where the check has no edge)
     uint64_t hlo[64];                    // parity-check row of the lane's check as masks over ballot(half 0), ballot(half 1)
     uint64_t hhi[64];
     uint8_t full[64];                    // the lane's check has 11 bits (ldpc_context.cuh:160-163)
@@ -64,12 +63,13 @@ constexpr EdgeTables make_edge_tables()
         t.hlo[l] = 0;
         t.hhi[l] = 0;
         t.full[l] = 0;
-        for(int r = 0; r < kMaxCheckDegree; r++) t.fwd[l][r] = kOneCell;
+        for(int r = 0; r < kMaxCheckDegree; r++) t.fwd[l][r] = kOnesBase;  // lanes >= 38 never read
     }
     for(int c = 0; c < kChecks; c++)
     {
         const int cl = kLaneOfCheck[c];
         t.full[cl] = kCheckBits[c][kMaxCheckDegree - 1] >= 0 ? 1 : 0;
+        if(!t.full[cl]) t.fwd[cl][kRoundOfSlot[c][kMaxCheckDegree - 1]] = kOneCellOfCheck[c];  // the empty round of a degree-10 check
         for(int j = 0; j < kMaxCheckDegree; j++)
         {
             const int n = kCheckBits[c][j];
@@ -90,7 +90,7 @@ constexpr EdgeTables make_edge_tables()
             {
                 // instructions 0 and 1 may take the bit's first two edges in either order: (tov0 + tov1) + tov2 is commutative in them
                 const int k = (i < 2 && kSwapFirstEdges[n]) ? 1 - i : i;
-                t.cell[h][l][i] = static_cast<uint16_t>(e_slot[n][k] * kTileRowStride + kLaneOfCheck[e_check[n][k]]);
+                t.cell[h][l][i] = static_cast<uint16_t>(kRowBase[e_slot[n][k]] + kLaneOfCheck[e_check[n][k]]);
                 t.fwd[kLaneOfCheck[e_check[n][k]]][e_slot[n][k]] = static_cast<uint16_t>((h * kEdgesPerBit + i) * 64 + l);
             }
         }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
 #pragma unroll
     for(int h = 0; h < 2; h++)
 #pragma unroll
-        for(int k = 0; k < kEdgesPerBit; k++) e_addr[h][k] = kBwdBase + kEdges.cell[h][lane][k];
+        for(int k = 0; k < kEdgesPerBit; k++) e_addr[h][k] = kEdges.cell[h][lane][k];
     // forward gather: the cell this check lane reads in round r (lanes >= 38 read the constant)
     const float* f_addr[kMaxCheckDegree];
 #pragma unroll
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
     // LDS byte address of this wave's tile, for the M0-relative column stores
     const uint32_t tile_m0 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) float*)T)));
 
-    // the eleventh factor of the degree-10 checks
-    if(lane == 0) T[kOneCell] = 1.0f;
+    // the eleventh factor of the degree-10 checks, once per bank
+    if(lane < 32) T[kOnesBase + lane] = 1.0f;
 
     // Software pipeline over this wave's codewords: the index entry of codeword n+2 and the two LLRs of codeword n+1 are
     // fetched while codeword n iterates, so a codeword starts without the two dependent global-memory latencies
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             // check node c (lane c): column T[0..10][c] -> leave-one-out products, in place
             if(lane < kChecks)
             {
-                // round r: the tanh of this check's edge of colour r, gathered from the bit-major tile; the rounds are an edge
-                // colouring of (check, bit lane mod 32), so the 32 lanes of a group never share a bank (ldpc_layout.h)
+                // round r: the tanh of this check's edge of round r, gathered from the bit-major tile; within a 32-lane group the
+                // real reads of a round sit on 32 different banks and the 1.0 reads on a bank they leave free (ldpc_layout.h)
                 float t[kMaxCheckDegree];
 #pragma unroll
                 for(int r = 0; r < kMaxCheckDegree; r++) t[r] = *f_addr[r];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                     out[j] = pre[j] * suf;
                     suf *= t[j];
                 }
-                // The column store is base + 4 r stride + 4 lane: ds_write_addtid_b32 takes that address from M0 + offset + 4*lane
+                // The column store is 4 kRowBase[r] + 4 lane: ds_write_addtid_b32 takes that address from M0 + offset + 4*lane
                 // and moves no address VGPR to the LDS.  A degree-10 check also stores the product of its empty round: no edge reads it.
                 static_assert(kMaxCheckDegree == 11, "eleven column stores below");
                 asm volatile("s_mov_b32 m0, %11\n\t"
@@ -382,9 +382,9 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
                              "ds_write_addtid_b32 %10 offset:%c22"
                              :
                              : "v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7]), "v"(out[8]), "v"(out[9]), "v"(out[10]),
-                               "s"(tile_m0), "n"((kBwdBase + 0 * kTStride) * 4), "n"((kBwdBase + 1 * kTStride) * 4), "n"((kBwdBase + 2 * kTStride) * 4),
-                               "n"((kBwdBase + 3 * kTStride) * 4), "n"((kBwdBase + 4 * kTStride) * 4), "n"((kBwdBase + 5 * kTStride) * 4), "n"((kBwdBase + 6 * kTStride) * 4),
-                               "n"((kBwdBase + 7 * kTStride) * 4), "n"((kBwdBase + 8 * kTStride) * 4), "n"((kBwdBase + 9 * kTStride) * 4), "n"((kBwdBase + 10 * kTStride) * 4)
+                               "s"(tile_m0), "n"(kRowBase[0] * 4), "n"(kRowBase[1] * 4), "n"(kRowBase[2] * 4),
+                               "n"(kRowBase[3] * 4), "n"(kRowBase[4] * 4), "n"(kRowBase[5] * 4), "n"(kRowBase[6] * 4),
+                               "n"(kRowBase[7] * 4), "n"(kRowBase[8] * 4), "n"(kRowBase[9] * 4), "n"(kRowBase[10] * 4)
                              : "memory");
             }
             __builtin_amdgcn_wave_barrier();

@@ -96,12 +96,40 @@ class RecordGather:
         self._recv_trailers = [t[self.nbytes:].view(torch.int32) for t in self.recv] if rank == 0 else None
         self.max_total = torch.zeros(world, dtype=torch.int32, device=device) if rank == 0 else None
         self.steps = 0
+        self._spans = []          # timed steps: (start, end) device events, or host seconds on a CPU backend
 
-    def step(self, rec_bytes, count_i32):
+    def step(self, rec_bytes, count_i32, timed: bool = False):
         """rec_bytes: uint8 view of the decoder's device record list (>= cap*52 bytes); count_i32: int32[1]
-        view of its device-side record count."""
+        view of its device-side record count.  timed: bracket this exchange (copy into the send buffer + gather) with events on
+        the current stream - the collective's own stream is joined to it by the blocking dist.gather - read later by mean_ms()."""
+        import time
+
         import torch
         import torch.distributed as dist
+        on_gpu = self.send.is_cuda
+        if timed:
+            if on_gpu:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            else:
+                t0 = time.perf_counter()
+        self._step(rec_bytes, count_i32, torch, dist)
+        if timed:
+            if on_gpu:
+                e1.record()
+                self._spans.append((e0, e1))
+            else:
+                self._spans.append((t0, time.perf_counter()))
+
+    def mean_ms(self) -> Optional[float]:
+        """Average duration of the timed exchanges on this rank (call after the stream has been synchronised)."""
+        if not self._spans:
+            return None
+        if self.send.is_cuda:
+            return float(sum(a.elapsed_time(b) for a, b in self._spans) / len(self._spans))
+        return float(sum(b - a for a, b in self._spans) / len(self._spans) * 1e3)
+
+    def _step(self, rec_bytes, count_i32, torch, dist):
         self.send[:self.nbytes].copy_(rec_bytes[:self.nbytes], non_blocking=True)
         self._trailer[1:2].copy_(count_i32, non_blocking=True)
         torch.clamp(count_i32, max=self.cap, out=self._trailer[0:1])

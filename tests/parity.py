@@ -210,3 +210,55 @@ def decoded_set(items):
 
 def decoded_messages(items):
     return {bytes(np.asarray(items["message"][k], dtype=np.uint8)) for k in np.nonzero(items["is_message_present"])[0]}
+
+
+def compare_result_list_with_oracle(o, orc_mod, records, analytic_by_channel):
+    """The compact result list of a decoder that does NOT retain candidates (the production path: blocked staging, gated softbits)
+    against the oracle's decode_window of the same channels: for every listed channel the set of (item, payload) must be the
+    oracle's, and every field of a matching record must agree (integers exact, f0 bit-equal, xb within tolerance).  A decode present
+    on one side only is tolerated ONLY as a verified marginal case: the slot's position differs (a scan near-tie, checked against
+    the oracle's own correlation values) with the payload still decoded elsewhere in the channel, or the oracle's BP decision
+    on that slot's LLRs flips under 1e-6..1e-4 perturbations."""
+    rec_by_channel = {}
+    for r in records:
+        rec_by_channel.setdefault(int(r["channel"]), []).append(r)
+    decodes = marginal = 0
+    notes = []
+    for ch, cd in analytic_by_channel.items():
+        items, _ = o.decode_window(cd)
+        want = {int(k): bytes(np.packbits(np.concatenate([items["message"][k].astype(np.uint8), np.zeros(3, np.uint8)])))
+                for k in np.nonzero(items["is_message_present"])[0]}
+        got = {int(r["item"]): r for r in rec_by_channel.get(ch, [])}
+        assert {bytes(r["message"]) for r in got.values()} == set(want.values()), ("payload sets differ", ch)
+        for k in sorted(set(want) | set(got)):
+            if k in want and k in got:
+                r = got[k]
+                assert bytes(r["message"]) == want[k], (ch, k)
+                if int(r["pos"]) == int(items["pos"][k]):
+                    assert int(r["nbadsync"]) == int(items["nbadsync"][k]) and int(r["ldpc_hard_errors"]) == int(items["ldpc_num_hard_errors"][k]), (ch, k)
+                    assert int(r["pattern_idx"]) == int(items["pattern_idx"][k]) and int(r["num_avg"]) == int(items["num_avg"][k]), (ch, k)
+                    assert np.float32(r["f0"]).view(np.uint32) == np.float32(items["f0"][k]).view(np.uint32), (ch, k)
+                    assert abs(float(r["xb"]) - float(items["xb"][k])) <= TOL_XB_REL * max(float(items["xb"][k]), 1e-30), (ch, k)
+                    if int(r["ldpc_iterations"]) != int(items["ldpc_num_iterations"][k]):
+                        scale = verify_marginal_bp(orc_mod, items["softbits_wo_sync"][k], (True, int(r["ldpc_iterations"])), seed=3000 + k)
+                        marginal += 1
+                        notes.append(dict(channel=ch, item=k, kind="iteration", unstable_at_relative_perturbation=scale))
+                decodes += 1
+                continue
+            b, p = int(items["block_idx"][k]), int(items["pattern_idx"][k])
+            if k in got and int(got[k]["pos"]) != int(items["pos"][k]):
+                ref = o.scan_xb(cd, b, p).astype(np.float64)
+                g0 = k - k % 8
+                po = items["pos"][g0:g0 + 8].astype(np.int64)
+                pg = po.copy()
+                pg[k % 8] = int(got[k]["pos"])
+                assert p in PERIODIC or _near_tie_sets(ref, po, pg, max(float(items["xb"][g0:g0 + 8].max()), 1e-30)), ("decode at a different position, not a near-tie", ch, k)
+                kind = "scan near-tie"
+                scale = None
+            else:
+                outcome = (True, int(got[k]["ldpc_iterations"])) if k in got else (False, -1)
+                scale = verify_marginal_bp(orc_mod, items["softbits_wo_sync"][k], outcome, seed=3000 + k)
+                kind = "bp"
+            marginal += 1
+            notes.append(dict(channel=ch, item=k, kind=kind, side="gpu only" if k in got else "oracle only", unstable_at_relative_perturbation=scale))
+    return dict(channels=len(analytic_by_channel), decodes=decodes, marginal=marginal, notes=notes)

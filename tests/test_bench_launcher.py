@@ -31,6 +31,11 @@ def test_gpus2_self_launch_reports_two_ranks():
     assert g["backend"] == "gloo" and g["records_last_step"] == 5 + 6                   # rank 0: 5 records, rank 1: 6
     assert g["peak_records_per_rank"] == [5, 6] and g["capacity_per_rank"] >= 1024
     assert out["value"] > 0 and out["steps"] == 3
+    # what a driver's --gpus N record must carry besides value: per-rank step times (value uses the MAX) and the gather alone
+    rk = out["rank_ms_per_step"]
+    assert len(rk["per_rank"]) == 2 and rk["min"] <= rk["max"] and abs(rk["max"] - out["ms_per_step"]) < 1e-6
+    assert g["ms_per_step"] is not None and g["ms_per_step"] >= 0.0
+    assert "roofline" in out and out["roofline"]["mode"]
 
 
 def test_gpus1_through_launcher_matches_contract():

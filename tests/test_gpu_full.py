@@ -41,7 +41,7 @@ def test_deep_window_against_oracle(orc, hip, parity_report):
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
 
 
-def test_1024_channel_batch_properties(orc, hip):
+def test_1024_channel_batch_properties(orc, hip, parity_report):
     """BASELINE configs[2] size: round trip of the injected pings, determinism, channel independence and
     agreement with the oracle on every payload that is not a transmitted one (CRC-13 false positives of the
     algorithm itself are expected at 1.6e7 BP attempts per step and must be the oracle's too)."""
@@ -57,6 +57,14 @@ def test_1024_channel_batch_properties(orc, hip):
         d.decode()
         res2 = d.results().copy()
     assert res1.tobytes() == res2.tobytes()                             # deterministic
+    # the PRODUCTION path - default blocked staging (64-channel blocks, softbits_kernel<true>: gated-out candidates stop after
+    # their sync check), what bench.py times - must give the retained-mode list byte for byte at full size
+    with hip.HipDecoder(channels=1024, max_results=1 << 20, **DEEP) as dp:
+        assert dp.params.llr_block_channels == 64
+        dp.submit_audio(wins[2])
+        dp.decode()
+        prod = dp.results().copy()
+    assert prod.tobytes() == res1.tobytes()
     key = res1["channel"].astype(np.int64) * 100000 + res1["item"]
     assert np.all(np.diff(key) > 0)                                     # ordered by (channel, item)
     decoded_channels = set(int(c) for c in np.unique(res1["channel"]))
@@ -76,6 +84,14 @@ def test_1024_channel_batch_properties(orc, hip):
             d1.submit_audio(wins[2, ch])
             d1.decode()
             assert d1.dump_candidates(0).tobytes() == blob              # batch == single, bit for bit
+    # production list against the oracle DIRECTLY: 16 sampled channels spread over the 64-channel blocks, eight with a decoded
+    # ping and eight noise-only - the set of (item, payload) must be the oracle's decode_window set
+    with_ping = sorted(decoded_channels & pinged)
+    noise = [c for c in range(1024) if c not in pinged]
+    sample = [with_ping[i * len(with_ping) // 8] for i in range(8)] + [noise[i * len(noise) // 8] for i in range(8)]
+    report = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_audio(wins[2, ch], 2) for ch in sample})
+    assert report["channels"] == 16 and report["decodes"] >= 8, report
+    parity_report("production_path_1024ch_vs_oracle", report)
 
 
 def test_fine_step_depth8_all_gated(orc, hip, parity_report):
@@ -124,6 +140,13 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
         d.decode()
         res2 = d.results().copy()
     assert res1.tobytes() == res2.tobytes()                             # deterministic
+    # production path (default 64-channel blocks, gated softbits) at full size: same list, byte for byte
+    with hip.HipDecoder(read_mode=2, channels=nch, max_results=1 << 20, **cfg) as dp:
+        assert dp.params.llr_block_channels == 64
+        dp.submit_iq(wins)
+        dp.decode()
+        prod = dp.results().copy()
+    assert prod.tobytes() == res1.tobytes()
     key = res1["channel"].astype(np.int64) * 100000 + res1["item"]
     assert np.all(np.diff(key) > 0)                                     # ordered by (channel, item)
     good = {int(r["channel"]) for r in res1 if truth.get(int(r["channel"])) == bytes(r["message"])}
@@ -152,6 +175,13 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
                 same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
                 ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
                 assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
+    # and against the oracle directly: 16 sampled channels (eight decoded pings, eight without a ping)
+    no_ping = [c for c in range(nch) if c not in truth]
+    gl = sorted(good)
+    sample = [gl[i * len(gl) // 8] for i in range(8)] + [no_ping[i * len(no_ping) // 8] for i in range(8)]
+    direct = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_iq(wins[ch]) for ch in sample})
+    assert direct["channels"] == 16 and direct["decodes"] >= 8, direct
+    parity_report("production_path_config4_vs_oracle", direct)
     parity_report("config4_iq_4096", dict(channels=nch, decodes=int(len(res1)), pinged=len(truth), pinged_decoded=len(good),
                                           not_transmitted=len(unexpected), channel0=dict(scan=rep, softbits=sb, ldpc=ld)))
 

@@ -1,20 +1,24 @@
 """Offline generator of msk144cudecoder_amd/csrc/ldpc_layout.h (developer tool, not part of the product).
 
-LDS traffic of one BP iteration in ldpc.hip:
-  forward  (bit -> check): lane (h, l) stores tanh of its edge of instruction i into the BIT-major tile cell (3h + i)*64 + l with
-           ds_write_addtid_b32 (no address VGPR, always conflict-free); check lane L then GATHERS its column with eleven ds_read_b32,
-           one per round r, from per-lane addresses.  Bank of a cell = lane of the bit mod 32, so the gather of round r is
-           conflict-free iff the checks of a 32-lane group read 32 different bit-lane residues: the rounds of a group are a proper
-           edge colouring of the bipartite multigraph (check, residue) with eleven colours, which exists iff no residue carries
-           more than eleven edges of the group (Koenig).
-  backward (check -> bit): check lane L stores its round-r product to cell r*S + L (M0-relative ds_write_addtid_b32), lane (h, l)
-           gathers the six cells of its edges: this side keeps bank conflicts, minimised here by local search.
-Freedom: bit -> (h, lane), first-two-edges order per bit, check -> lane, and the colouring itself (Kempe chains).
+The search itself is tools/layout/anneal_rounds.cpp (simulated annealing over bit -> lane, first-edge order, check -> lane, the
+round of every edge at its check and the bank residue of every backward row); this script turns its result into the header:
+it places the backward rows (first-fit, each at its residue mod 32), gives every empty round of a degree-10 check a constant-1.0
+cell on a bank no real read of the same (round, 32-lane group) access uses, re-counts every conflict with the full-address
+model below and quotes the counts in the header (tests/test_ldpc_layout.py re-derives them from the emitted tables).
 
-    python tools/layout/make_layout.py [seed] [iterations]  > msk144cudecoder_amd/csrc/ldpc_layout.h
+LDS traffic of one BP iteration in ldpc.hip (per wave; cells are floats, bank = cell mod 32, a ds_read_b32 is served as two
+groups of 32 lanes, N distinct addresses on one bank = N cycles, equal addresses broadcast):
+  forward  (bit -> check): lane (h, l) stores the tanh of its edge of instruction i to cell (3h + i)*64 + l (add-TID store, never
+           conflicted); check lane L gathers one factor per round r - a real edge's cell, or, in the empty round of a degree-10
+           check, one of the 32 constant-1.0 cells kOnesBase + b;
+  backward (check -> bit): check lane L stores its round-r product to cell kRowBase[r] + L (add-TID store); lane (h, l) gathers the
+           six cells of its edges.
+
+    g++ -O2 -o /tmp/anneal_rounds tools/layout/anneal_rounds.cpp
+    /tmp/anneal_rounds tools/layout/edges.txt SEED ITERATIONS > /tmp/layout.txt
+    python tools/layout/make_layout.py /tmp/layout.txt > msk144cudecoder_amd/csrc/ldpc_layout.h
 """
 import os
-import random
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,192 +30,140 @@ EDGES = [[] for _ in range(128)]          # bit -> [(slot j, check c)] in ascend
 for c, r in enumerate(ROWS):
     for j, n in enumerate(r):
         EDGES[n].append((j, c))
-S = 38                                     # backward tile row stride
 ROUNDS = 11
+ROW_CELLS = 38                             # one backward row = one cell per check lane
+FWD_CELLS = 2 * 3 * 64                     # bit-major forward tile
+ONES_BASE = FWD_CELLS                      # 32 cells of 1.0, cell ONES_BASE + b sits on bank b (384 = 12 * 32)
 
 
-def colour_group(checks, bank_of_edge):
-    """Proper edge colouring (rounds) of the bipartite multigraph check x bank for the listed checks.
-    bank_of_edge[(c, j)] -> bank.  Returns {(c, j): round} or None if a bank has more than ROUNDS edges."""
-    at_check = {c: [None] * ROUNDS for c in checks}     # colour -> edge
-    at_bank = {}
-    edges = [(c, j) for c in checks for j in range(len(ROWS[c]))]
-    deg = {}
-    for e in edges:
-        deg[bank_of_edge[e]] = deg.get(bank_of_edge[e], 0) + 1
-    if max(deg.values()) > ROUNDS:
-        return None
-    colour = {}
-    for e in edges:
-        c, b = e[0], bank_of_edge[e]
-        tb = at_bank.setdefault(b, [None] * ROUNDS)
-        tc = at_check[c]
-        fa = next(k for k in range(ROUNDS) if tc[k] is None)     # free at the check
-        fb = next(k for k in range(ROUNDS) if tb[k] is None)     # free at the bank
-        if tb[fa] is not None:
-            # alternating path from the bank along colours fa / fb: swap them on the path
-            path, node_is_bank, node, col = [], True, b, fa
-            while True:
-                tab = at_bank[node] if node_is_bank else at_check[node]
-                nxt = tab[col]
-                if nxt is None:
-                    break
-                path.append(nxt)
-                node = nxt[0] if node_is_bank else bank_of_edge[nxt]
-                node_is_bank = not node_is_bank
-                col = fb if col == fa else fa
-            for pe in path:                                   # remove, then re-insert with swapped colours
-                k = colour[pe]
-                at_check[pe[0]][k] = None
-                at_bank[bank_of_edge[pe]][k] = None
-            for pe in path:
-                k = fb if colour[pe] == fa else fa
-                colour[pe] = k
-                at_check[pe[0]][k] = pe
-                at_bank[bank_of_edge[pe]][k] = pe
-        assert tc[fa] is None and tb[fa] is None
-        colour[e] = fa
-        tc[fa] = e
-        tb[fa] = e
-    return colour
+def write_edges_file(path):
+    with open(path, "w") as f:
+        for n in range(128):
+            f.write(" ".join(f"{j} {c}" for j, c in EDGES[n]) + "\n")
+
+
+def cycles(addresses):
+    """Extra LDS cycles of one 32-lane access: max over banks of the number of DISTINCT addresses, minus one."""
+    per_bank = {}
+    for a in addresses:
+        per_bank.setdefault(a % 32, set()).add(a)
+    return max((len(v) for v in per_bank.values()), default=1) - 1
 
 
 class Layout:
-    def __init__(self, rng):
-        self.rng = rng
-        self.bit_at = list(range(128))
-        rng.shuffle(self.bit_at)
-        self.swap = [rng.randrange(2) for _ in range(128)]
-        self.loc = list(range(38))
-        rng.shuffle(self.loc)
-        self.round = None
+    def __init__(self, bit_at, swap, loc, rounds, row_base, one_cell):
+        self.bit_at, self.swap, self.loc, self.rounds, self.row_base, self.one_cell = bit_at, swap, loc, rounds, row_base, one_cell
 
-    def pos_of_bit(self):
-        pos = [0] * 128
-        for p, n in enumerate(self.bit_at):
-            pos[n] = p
-        return pos
+    def edge_of_instruction(self, pos, i):
+        n = self.bit_at[pos]
+        k = 1 - i if (i < 2 and self.swap[n]) else i
+        return EDGES[n][k]
 
-    def colour(self):
-        pos = self.pos_of_bit()
-        bank = {(c, j): (pos[n] % 64) % 32 for c, r in enumerate(ROWS) for j, n in enumerate(r)}
-        g0 = [c for c in range(38) if self.loc[c] < 32]
-        g1 = [c for c in range(38) if self.loc[c] >= 32]
-        a, b = colour_group(g0, bank), colour_group(g1, bank)
-        if a is None or b is None:
-            return False
-        a.update(b)
-        self.round = a
-        return True
+    def forward_cell(self):
+        """(check, slot) -> forward-tile cell its tanh is stored to."""
+        cell = {}
+        for pos in range(128):
+            h, l = divmod(pos, 64)
+            for i in range(3):
+                j, c = self.edge_of_instruction(pos, i)
+                cell[(c, j)] = (3 * h + i) * 64 + l
+        return cell
 
-    def forward_conflicts(self):
-        pos = self.pos_of_bit()
-        extra = 0
-        for r in range(ROUNDS):
-            for grp in (0, 1):
-                seen = {}
-                for c in range(38):
-                    if (self.loc[c] >= 32) != bool(grp):
-                        continue
-                    for j, n in enumerate(ROWS[c]):
-                        if self.round[(c, j)] == r:
-                            b = (pos[n] % 64) % 32
-                            seen.setdefault(b, set()).add(pos[n])
-                if seen:
-                    extra += max(len(v) for v in seen.values()) - 1
-        return extra
+    def forward_reads(self, one_cell=None):
+        """Addresses of the eleven gathers of the check lanes: {(round, group): [cell of every active lane]}."""
+        one_cell = self.one_cell if one_cell is None else one_cell
+        cell = self.forward_cell()
+        acc = {(r, g): [] for r in range(ROUNDS) for g in range(2)}
+        for c, row in enumerate(ROWS):
+            g = int(self.loc[c] >= 32)
+            for j in range(ROUNDS):
+                r = self.rounds[c][j]
+                acc[(r, g)].append(cell[(c, j)] if j < len(row) else one_cell[c])
+        return acc
 
-    def backward_cost(self):
-        """(conflicted cycles, colliding pairs) of the six gather instructions x two groups."""
-        cyc = pairs = 0
+    def forward_conflicts(self, one_cell=None):
+        return sum(cycles(a) for a in self.forward_reads(one_cell).values())
+
+    def backward_conflicts(self):
+        total = 0
         for h in range(2):
             for i in range(3):
                 for g in range(2):
-                    cnt = [0] * 32
+                    adr = []
                     for lane in range(32 * g, 32 * g + 32):
-                        n = self.bit_at[h * 64 + lane]
-                        k = 1 - i if (i < 2 and self.swap[n]) else i
-                        j, c = EDGES[n][k]
-                        cnt[(self.round[(c, j)] * S + self.loc[c]) % 32] += 1
-                    cyc += max(cnt) - 1
-                    pairs += sum(x * (x - 1) // 2 for x in cnt)
-        return cyc, pairs
+                        j, c = self.edge_of_instruction(h * 64 + lane, i)
+                        adr.append(self.row_base[self.rounds[c][j]] + self.loc[c])
+                    total += cycles(adr)
+        return total
 
 
-def search(seed, iters):
-    rng = random.Random(seed)
-    while True:
-        lay = Layout(rng)
-        if lay.colour():
-            break
-    assert lay.forward_conflicts() == 0
-    def score():
-        c, p = lay.backward_cost()
-        return c + 0.25 * p
-    cur = score()
-    best = (cur, list(lay.bit_at), list(lay.swap), list(lay.loc), dict(lay.round))
-    t0, t1 = 1.0, 0.05
-    for it in range(iters):
-        temp = t0 * (t1 / t0) ** (it / iters)
-        r = rng.random()
-        if r < 0.5:
-            n = rng.randrange(128)
-            lay.swap[n] ^= 1
-            new = score()
-            if new <= cur or rng.random() < pow(2.718281828, (cur - new) / temp):
-                cur = new
-            else:
-                lay.swap[n] ^= 1
-        else:
-            # move a whole layout element and recolour: two bits trade places, or two checks trade lanes
-            sb, sl, sr = list(lay.bit_at), list(lay.loc), dict(lay.round)
-            if r < 0.85:
-                a, b = rng.randrange(128), rng.randrange(128)
-                lay.bit_at[a], lay.bit_at[b] = lay.bit_at[b], lay.bit_at[a]
-            else:
-                a, b = rng.randrange(38), rng.randrange(38)
-                lay.loc[a], lay.loc[b] = lay.loc[b], lay.loc[a]
-            ok = lay.colour()
-            new = score() if ok else None
-            if ok and (new <= cur or rng.random() < pow(2.718281828, (cur - new) / temp)):
-                cur = new
-            else:
-                lay.bit_at, lay.loc, lay.round = sb, sl, sr
-        if cur < best[0]:
-            best = (cur, list(lay.bit_at), list(lay.swap), list(lay.loc), dict(lay.round))
-    lay.bit_at, lay.swap, lay.loc, lay.round = best[1], best[2], best[3], best[4]
+def place_rows(residue, first_free):
+    """Row bases at the wanted residues mod 32, rows of ROW_CELLS cells, first-fit: at each step the row that pads least."""
+    base, nxt, left = [None] * ROUNDS, first_free, set(range(ROUNDS))
+    while left:
+        r = min(left, key=lambda q: ((residue[q] - nxt) % 32, q))
+        base[r] = nxt + (residue[r] - nxt) % 32
+        nxt = base[r] + ROW_CELLS
+        left.remove(r)
+    return base, nxt
+
+
+def assign_one_cells(lay):
+    """A constant-1.0 cell for the empty round of every degree-10 check: one bank per (round, group) access that none of its real
+    reads uses (all empty lanes of the access share the address: a broadcast)."""
+    real = lay.forward_reads(one_cell=[None] * 38)
+    one = [0] * 38
+    for c, row in enumerate(ROWS):
+        if len(row) == ROUNDS:
+            continue
+        key = (lay.rounds[c][ROUNDS - 1], int(lay.loc[c] >= 32))
+        used = {a % 32 for a in real[key] if a is not None}
+        one[c] = ONES_BASE + min(b for b in range(32) if b not in used)
+    return one
+
+
+def natural_layout():
+    rounds = [list(range(ROUNDS)) for _ in range(38)]
+    lay = Layout(list(range(128)), [0] * 128, list(range(38)), rounds, [ONES_BASE + 8 + r * ROW_CELLS for r in range(ROUNDS)], [ONES_BASE] * 38)
+    return lay
+
+
+def read_search_result(path):
+    rec = {}
+    for line in open(path):
+        w = line.split()
+        if w:
+            rec[w[0]] = [int(x) for x in w[1:]] if w[0] != "seed" else w[1:]
+    rounds = [rec["rounds"][11 * c:11 * c + 11] for c in range(38)]
+    row_base, end = place_rows(rec["rowres"], ONES_BASE + 32)
+    lay = Layout(rec["bits"], rec["swap"], rec["loc"], rounds, row_base, None)
+    lay.one_cell = assign_one_cells(lay)
+    lay.tile_cells = end
     return lay
 
 
 def emit(lay):
-    cyc, pairs = lay.backward_cost()
-    assert lay.forward_conflicts() == 0
-    # round of every (check, slot); the unused round of a degree-10 check is the round of its missing slot 10
-    rounds = []
-    for c, r in enumerate(ROWS):
-        used = [lay.round[(c, j)] for j in range(len(r))]
-        assert len(set(used)) == len(used)
-        free = [k for k in range(ROUNDS) if k not in used]
-        rounds.append(used + free)
-    nat = Layout(random.Random(0))
-    nat.bit_at, nat.swap, nat.loc = list(range(128)), [0] * 128, list(range(38))
-    nat.round = {(c, j): j for c, r in enumerate(ROWS) for j in range(len(r))}
-    ncyc, _ = nat.backward_cost()
-    nfwd = nat.forward_conflicts()
+    fwd, bwd = lay.forward_conflicts(), lay.backward_conflicts()
+    nat = natural_layout()
+    nfwd, nbwd = nat.forward_conflicts(), nat.backward_conflicts()
+    single = lay.forward_conflicts(one_cell=[ONES_BASE] * 38)
     out = []
-    out.append("// GENERATED by tools/layout/make_layout.py (edge colouring + local search over the bit -> lane, check -> lane, first-edge-order")
-    out.append("// and round assignments); tests/test_ldpc_layout.py re-derives the conflict counts from these tables with the LDS bank rules")
-    out.append("// of MI355X_MICROARCH.md (ds_read_b32: two 32-lane groups, 32 banks of 4 bytes, N distinct addresses on a bank = N cycles).")
+    out.append("// GENERATED by tools/layout/make_layout.py from a result of tools/layout/anneal_rounds.cpp (simulated annealing over the bit -> lane,")
+    out.append("// check -> lane, first-edge-order and round assignments and the bank residues of the backward rows); tests/test_ldpc_layout.py")
+    out.append("// re-derives the conflict counts from these tables with the LDS bank rules of MI355X_MICROARCH.md (ds_read_b32: two 32-lane")
+    out.append("// groups, 32 banks of 4 bytes, N distinct addresses on a bank = N cycles, equal addresses broadcast) over the full addresses of")
+    out.append("// EVERY read the kernel issues, the constant-1.0 reads of the degree-10 checks included.")
     out.append("//")
     out.append("// LDS layout of the BP messages (ldpc.hip): lane l owns codeword bits kBitOfLane[0][l] and kBitOfLane[1][l]; check c is")
     out.append("// processed by lane kLaneOfCheck[c]; kSwapFirstEdges[n] = 1: instruction 0 takes bit n's second edge and instruction 1 its")
     out.append("// first - free, their messages are only ever added to each other first ((tov0 + tov1) + tov2).")
     out.append("//   forward (bit -> check): instruction i of half h stores to the bit-major cell (3h + i)*64 + lane (add-TID store, conflict-free);")
-    out.append("//     check lane L reads its edge of round r = kRoundOfSlot[c][j] (j = position of the bit in the check's row): the rounds are")
-    out.append("//     a proper edge colouring of (check, bit lane mod 32) within each 32-lane group of checks, so every gather is conflict-free;")
-    out.append("//   backward (check -> bit): the product of round r goes to cell r*kTileRowStride + L; the bit side gathers its six cells.")
-    out.append(f"// Forward gather: {lay.forward_conflicts()} extra LDS cycles per iteration (rounds = row order on the natural layout: {nfwd}).")
-    out.append(f"// Backward gather: {cyc} extra LDS cycles per iteration (natural layout, bit n in lane n % 64, rounds = row order: {ncyc}).")
+    out.append("//     check lane L reads its edge of round r = kRoundOfSlot[c][j] (j = position of the bit in the check's row).  In its empty")
+    out.append("//     round (kRoundOfSlot[c][10] of a degree-10 check) it reads the constant 1.0 at kOneCellOfCheck[c]: one of the 32 cells")
+    out.append("//     kOnesBase + b, b = a bank no real read of the same (round, 32-lane group) access uses;")
+    out.append("//   backward (check -> bit): the product of round r goes to cell kRowBase[r] + L; the bit side gathers its six cells.")
+    out.append(f"// Forward gather: {fwd} extra LDS cycles per iteration (natural layout, rounds = row order, one 1.0 cell: {nfwd}; these tables with a single 1.0 cell on bank 0: {single}).")
+    out.append(f"// Backward gather: {bwd} extra LDS cycles per iteration (natural layout, bit n in lane n % 64, rows 38 cells apart: {nbwd}).")
     out.append("#pragma once")
     out.append("")
     out.append("#include <cstdint>")
@@ -219,7 +171,9 @@ def emit(lay):
     out.append("namespace msk144")
     out.append("{")
     out.append("")
-    out.append(f"constexpr int kTileRowStride = {S};")
+    out.append(f"constexpr int kOnesBase = {ONES_BASE};      // 32 cells of 1.0, one per bank")
+    out.append(f"constexpr int kTileCells = {lay.tile_cells};     // floats per wave: forward tile, ones, backward rows")
+    out.append("constexpr uint16_t kRowBase[11] = {" + ", ".join(str(x) for x in lay.row_base) + "};")
     out.append("constexpr uint8_t kBitOfLane[2][64] = {")
     for h in range(2):
         out.append("    {" + ", ".join(str(x) for x in lay.bit_at[64 * h:64 * h + 64]) + "},")
@@ -228,16 +182,18 @@ def emit(lay):
     out.append("constexpr uint8_t kLaneOfCheck[38] = {" + ", ".join(str(x) for x in lay.loc) + "};")
     out.append("constexpr uint8_t kRoundOfSlot[38][11] = {")
     for c in range(38):
-        out.append("    {" + ", ".join(str(x) for x in rounds[c]) + "},")
+        out.append("    {" + ", ".join(str(x) for x in lay.rounds[c]) + "},")
     out.append("};")
+    out.append("constexpr uint16_t kOneCellOfCheck[38] = {" + ", ".join(str(x) for x in lay.one_cell) + "};  // 0: the check has eleven bits")
     out.append("")
     out.append("}  // namespace msk144")
     return "\n".join(out) + "\n"
 
 
 if __name__ == "__main__":
-    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
-    lay = search(seed, iters)
-    sys.stderr.write(f"seed {seed}: backward {lay.backward_cost()} forward {lay.forward_conflicts()}\n")
-    sys.stdout.write(emit(lay))
+    if len(sys.argv) == 3 and sys.argv[1] == "--edges":
+        write_edges_file(sys.argv[2])
+    else:
+        lay = read_search_result(sys.argv[1])
+        sys.stderr.write(f"forward {lay.forward_conflicts()} backward {lay.backward_conflicts()} tile {lay.tile_cells} floats\n")
+        sys.stdout.write(emit(lay))
