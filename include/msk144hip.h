@@ -16,6 +16,8 @@
  *                                                                 main.cu:477-484
  *   msk144_segment_power     the 8 segment powers SNRTracker::process_data sums from the analytic
  *                            window                               snr_tracker.cu:21-37, main.cu:388
+ *   msk144_input_slot ..     the same hop, pipelined over two pinned staging slots (fread buffer -> H2D -> kernels ->
+ *   msk144_fetch_wait        D2H of what the host loop consumes)  main.cu:261-422, 474-525
  *   msk144_dump_candidates   the raw ResultItem array (parity/debug)     result_keeper.cuh:17-32,123-130
  *   msk144_destroy           ~MSK144SearchContext / deinit        msk_context.cuh:81-120
  *
@@ -27,6 +29,7 @@
 #ifndef MSK144HIP_H
 #define MSK144HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -70,8 +73,12 @@ enum
     MSK144_T_INDEX = 3,
     MSK144_T_LDPC = 4,
     MSK144_T_COLLECT = 5,
-    MSK144_T_COUNT = 6
+    MSK144_T_H2D = 6,  /* host -> device copy of the submitted windows (msk144_submit_audio/_iq/_slot) */
+    MSK144_T_D2H = 7,  /* device -> host copy of count, records and segment powers (msk144_fetch_async) */
+    MSK144_T_COUNT = 8
 };
+
+#define MSK144_SLOTS 2 /* pinned staging slots per handle (msk144_input_slot .. msk144_fetch_wait) */
 
 typedef struct msk144_params
 {
@@ -175,6 +182,31 @@ int msk144_results_device(msk144_handle* h, const msk144_result** d_records, con
 int msk144_set_channel_base(msk144_handle* h, int32_t base);
 
 int msk144_segment_power(msk144_handle* h, float* out /*[channels][8]*/);
+
+/* Pinned staging, two slots ("handle owns device + pinned host buffers").  The reference's loop is strictly serial
+ * per hop - fread, H2D, kernels, cudaDeviceSynchronize, 15 MB D2H, host loop, print (main.cu:261-422, 461-525).  With the slots a
+ * caller fills the windows of hop n+1 and reads the results of hop n-1 while the GPU decodes hop n, and one hop costs one
+ * asynchronous H2D and one asynchronous D2H of exactly what the host loop consumes (count, compact records, 8 segment powers per
+ * channel) instead of five blocking calls:
+ *
+ *     msk144_input_slot(h, s, &win, &bytes);   fill win[channels][5184] (int16) or [channels][2*5184] (int8), pinned
+ *     msk144_submit_slot(h, s);                H2D + front end                      (asynchronous)
+ *     msk144_decode(h);                        kernels; the record list of slot s   (asynchronous)
+ *     msk144_fetch_async(h, s);                D2H into the slot's pinned output    (asynchronous)
+ *     ... other work, e.g. the same four calls for slot 1 - s ...
+ *     msk144_fetch_wait(h, s, &rec, &n, &seg); blocks until slot s has arrived; rec/seg point into the slot (valid until the slot
+ *                                              is submitted again)
+ *
+ * Each slot has its own device-side record list, so the list of slot s stays intact while slot 1 - s decodes.  The asynchronous
+ * copy covers a running estimate of the record count (twice the last count, at least 1024); msk144_fetch_wait copies a
+ * remainder synchronously.  The buffers are allocated at the first msk144_input_slot / msk144_fetch_async call of a handle.
+ * msk144_fetch_wait may be called from a second thread while the first thread submits the OTHER slot; everything else about a
+ * handle stays single-threaded.  msk144_fetch_wait returns MSK144_EOVERFLOW (records truncated to max_results) like
+ * msk144_results. */
+int msk144_input_slot(msk144_handle* h, int32_t slot, void** host_windows, size_t* bytes);
+int msk144_submit_slot(msk144_handle* h, int32_t slot);
+int msk144_fetch_async(msk144_handle* h, int32_t slot);
+int msk144_fetch_wait(msk144_handle* h, int32_t slot, const msk144_result** records, int32_t* n, const float** seg_power /*[channels][8]*/);
 
 /* parity / debug */
 int msk144_dump_analytic(msk144_handle* h, int32_t channel, float* out /*[5184][2]*/);

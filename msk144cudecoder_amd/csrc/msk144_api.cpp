@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -56,6 +57,25 @@ struct msk144_handle
     hipEvent_t ev_open = nullptr;
     double t_sum[MSK144_T_COUNT]{};
     int t_cnt[MSK144_T_COUNT]{};
+
+    // Pinned staging slots (msk144_input_slot .. msk144_fetch_wait), allocated on first use.  Slot 0's device record list is
+    // st.results of the plain calls; slot 1 has its own, so the list of one slot survives the decode of the other.
+    struct Slot
+    {
+        void* in = nullptr;                 // pinned windows, input_bytes()
+        msk144_result* d_records = nullptr; // device record list this slot's decode writes
+        msk144_result* out = nullptr;       // pinned records, max_results
+        int32_t* out_count = nullptr;       // pinned
+        float* out_seg = nullptr;           // pinned [channels][8]
+        int32_t copied = 0;                 // records covered by the asynchronous copy
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    };
+    Slot slots[MSK144_SLOTS];
+    bool slots_ready = false;
+    int cur_slot = 0;                        // the slot whose record list the next decode writes
+    std::atomic<int32_t> last_total{0};      // record count of the last fetched hop: sizes the next asynchronous copy
+    hipStream_t copy_stream = nullptr;       // remainder copies of msk144_fetch_wait (may run on a second thread)
 
     std::string error;
 };
@@ -158,9 +178,55 @@ void harvest_times(msk144_handle* h)
     h->spans_pending.clear();
 }
 
+int host_alloc(msk144_handle* h, void** p, size_t bytes)
+{
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    if(e != hipSuccess)
+    {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        return fail(h, MSK144_ENOMEM, buf);
+    }
+    return MSK144_OK;
+}
+
+int ensure_slots(msk144_handle* h)
+{
+    if(h->slots_ready) return MSK144_OK;
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    if(!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for(int s = 0; s < MSK144_SLOTS; s++)
+    {
+        msk144_handle::Slot& sl = h->slots[s];
+        int rc = MSK144_OK;
+        if(!sl.in) rc = host_alloc(h, &sl.in, input_bytes(h));
+        if(rc == MSK144_OK && !sl.out) rc = host_alloc(h, reinterpret_cast<void**>(&sl.out), sizeof(msk144_result) * static_cast<size_t>(h->st.max_results));
+        if(rc == MSK144_OK && !sl.out_count) rc = host_alloc(h, reinterpret_cast<void**>(&sl.out_count), sizeof(int32_t));
+        if(rc == MSK144_OK && !sl.out_seg) rc = host_alloc(h, reinterpret_cast<void**>(&sl.out_seg), sizeof(float) * 8 * h->st.channels);
+        if(rc != MSK144_OK) return rc;
+        if(!sl.d_records)
+        {
+            if(s == 0) sl.d_records = static_cast<msk144_result*>(h->st.results);
+            else if((rc = dev_alloc(h, &sl.d_records, h->st.max_results)) != MSK144_OK) return rc;
+        }
+        // blocking-sync event: the waiting thread sleeps instead of spinning on a core the ingest thread needs
+        if(!sl.done) HIP_TRY(h, hipEventCreateWithFlags(&sl.done, hipEventBlockingSync | hipEventDisableTiming));
+    }
+    h->slots_ready = true;
+    return MSK144_OK;
+}
+
+int copy_windows_in(msk144_handle* h, const void* host_windows)
+{
+    ev_begin(h, MSK144_T_H2D);
+    hipError_t e = hipMemcpyAsync(h->d_input, host_windows, input_bytes(h), hipMemcpyHostToDevice, h->stream);
+    ev_end(h, MSK144_T_H2D);
+    if(e != hipSuccess) return fail(h, MSK144_EHIP, std::string("hipMemcpyAsync(windows): ") + hipGetErrorString(e));
+    return MSK144_OK;
+}
+
 int run_frontend(msk144_handle* h, const void* d_in)
 {
-    h->call_id++;
     ev_begin(h, MSK144_T_FRONTEND);
     if(h->params.read_mode == 2) launch_frontend_iq(h->st, static_cast<const int8_t*>(d_in), h->stream);
     else launch_frontend_audio(h->st, static_cast<const int16_t*>(d_in), h->params.analytic_method, h->d_twiddle, h->d_fft_mask, h->stream);
@@ -350,6 +416,15 @@ void msk144_destroy(msk144_handle* h)
     if(!h) return;
     if(h->stream) (void)hipStreamSynchronize(h->stream);
     for(void* p : h->allocs) (void)hipFree(p);
+    for(auto& sl : h->slots)
+    {
+        if(sl.in) (void)hipHostFree(sl.in);
+        if(sl.out) (void)hipHostFree(sl.out);
+        if(sl.out_count) (void)hipHostFree(sl.out_count);
+        if(sl.out_seg) (void)hipHostFree(sl.out_seg);
+        if(sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if(h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for(const auto& sp : h->spans_pending)
     {
         (void)hipEventDestroy(sp.e0);
@@ -391,8 +466,10 @@ int msk144_submit_audio(msk144_handle* h, const int16_t* windows)
     if(!h || !windows) return fail(h, MSK144_EINVAL, "null argument");
     if(h->params.read_mode != 1) return fail(h, MSK144_ESTATE, "handle was created for IQ input (read_mode 2)");
     HIP_TRY(h, hipSetDevice(h->params.device));
-    HIP_TRY(h, hipMemcpyAsync(h->d_input, windows, input_bytes(h), hipMemcpyHostToDevice, h->stream));
-    return run_frontend(h, h->d_input);
+    h->call_id++;
+    h->cur_slot = 0;
+    int rc = copy_windows_in(h, windows);
+    return rc == MSK144_OK ? run_frontend(h, h->d_input) : rc;
 }
 
 int msk144_submit_iq(msk144_handle* h, const int8_t* windows)
@@ -400,8 +477,10 @@ int msk144_submit_iq(msk144_handle* h, const int8_t* windows)
     if(!h || !windows) return fail(h, MSK144_EINVAL, "null argument");
     if(h->params.read_mode != 2) return fail(h, MSK144_ESTATE, "handle was created for audio input (read_mode 1)");
     HIP_TRY(h, hipSetDevice(h->params.device));
-    HIP_TRY(h, hipMemcpyAsync(h->d_input, windows, input_bytes(h), hipMemcpyHostToDevice, h->stream));
-    return run_frontend(h, h->d_input);
+    h->call_id++;
+    h->cur_slot = 0;
+    int rc = copy_windows_in(h, windows);
+    return rc == MSK144_OK ? run_frontend(h, h->d_input) : rc;
 }
 
 int msk144_submit_audio_device(msk144_handle* h, const int16_t* d_windows)
@@ -409,6 +488,8 @@ int msk144_submit_audio_device(msk144_handle* h, const int16_t* d_windows)
     if(!h || !d_windows) return fail(h, MSK144_EINVAL, "null argument");
     if(h->params.read_mode != 1) return fail(h, MSK144_ESTATE, "handle was created for IQ input (read_mode 2)");
     HIP_TRY(h, hipSetDevice(h->params.device));
+    h->call_id++;
+    h->cur_slot = 0;
     return run_frontend(h, d_windows);
 }
 
@@ -417,6 +498,8 @@ int msk144_submit_iq_device(msk144_handle* h, const int8_t* d_windows)
     if(!h || !d_windows) return fail(h, MSK144_EINVAL, "null argument");
     if(h->params.read_mode != 2) return fail(h, MSK144_ESTATE, "handle was created for audio input (read_mode 1)");
     HIP_TRY(h, hipSetDevice(h->params.device));
+    h->call_id++;
+    h->cur_slot = 0;
     return run_frontend(h, d_windows);
 }
 
@@ -477,8 +560,10 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
     }
     if(stages & MSK144_STAGE_COLLECT)
     {
+        DeviceStore out = h->st;
+        if(h->slots_ready) out.results = h->slots[h->cur_slot].d_records;  // the record list of the slot being decoded
         ev_begin(h, MSK144_T_COLLECT);
-        launch_collect(h->st, h->stream);
+        launch_collect(out, h->stream);
         ev_end(h, MSK144_T_COLLECT);
     }
     HIP_TRY(h, hipGetLastError());
@@ -518,7 +603,8 @@ int msk144_results(msk144_handle* h, msk144_result* out, int32_t cap, int32_t* n
     *n = total;
     int32_t avail = total < h->st.max_results ? total : h->st.max_results;
     int32_t ncopy = avail < cap ? avail : cap;
-    if(ncopy > 0) HIP_TRY(h, hipMemcpy(out, h->st.results, sizeof(msk144_result) * ncopy, hipMemcpyDeviceToHost));
+    const void* list = h->slots_ready ? h->slots[h->cur_slot].d_records : h->st.results;  // the list the last decode wrote
+    if(ncopy > 0) HIP_TRY(h, hipMemcpy(out, list, sizeof(msk144_result) * ncopy, hipMemcpyDeviceToHost));
     if(total > h->st.max_results) return fail(h, MSK144_EOVERFLOW, "more decodes than max_results; list truncated");
     return MSK144_OK;
 }
@@ -526,7 +612,7 @@ int msk144_results(msk144_handle* h, msk144_result* out, int32_t cap, int32_t* n
 int msk144_results_device(msk144_handle* h, const msk144_result** d_records, const int32_t** d_count)
 {
     if(!h || !d_records || !d_count) return fail(h, MSK144_EINVAL, "null argument");
-    *d_records = static_cast<const msk144_result*>(h->st.results);
+    *d_records = h->slots_ready ? h->slots[h->cur_slot].d_records : static_cast<const msk144_result*>(h->st.results);
     *d_count = h->st.result_count;
     return MSK144_OK;
 }
@@ -547,6 +633,79 @@ int msk144_segment_power(msk144_handle* h, float* out)
     if(rc != MSK144_OK) return rc;
     HIP_TRY(h, hipMemcpy(out, h->st.seg_power, sizeof(float) * 8 * h->st.channels, hipMemcpyDeviceToHost));
     return MSK144_OK;
+}
+
+int msk144_input_slot(msk144_handle* h, int32_t slot, void** host_windows, size_t* bytes)
+{
+    if(!h || !host_windows || slot < 0 || slot >= MSK144_SLOTS) return fail(h, MSK144_EINVAL, "bad argument");
+    int rc = ensure_slots(h);
+    if(rc != MSK144_OK) return rc;
+    *host_windows = h->slots[slot].in;
+    if(bytes) *bytes = input_bytes(h);
+    return MSK144_OK;
+}
+
+int msk144_submit_slot(msk144_handle* h, int32_t slot)
+{
+    if(!h || slot < 0 || slot >= MSK144_SLOTS) return fail(h, MSK144_EINVAL, "bad argument");
+    int rc = ensure_slots(h);
+    if(rc != MSK144_OK) return rc;
+    if(h->slots[slot].pending) return fail(h, MSK144_ESTATE, "slot submitted again before its results were fetched (msk144_fetch_wait)");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    h->call_id++;
+    h->cur_slot = slot;
+    rc = copy_windows_in(h, h->slots[slot].in);
+    return rc == MSK144_OK ? run_frontend(h, h->d_input) : rc;
+}
+
+int msk144_fetch_async(msk144_handle* h, int32_t slot)
+{
+    if(!h || slot < 0 || slot >= MSK144_SLOTS) return fail(h, MSK144_EINVAL, "bad argument");
+    if(!h->decoded) return fail(h, MSK144_ESTATE, "no decode has been run");
+    int rc = ensure_slots(h);
+    if(rc != MSK144_OK) return rc;
+    if(slot != h->cur_slot) return fail(h, MSK144_ESTATE, "fetch of a slot other than the one just decoded");
+    msk144_handle::Slot& sl = h->slots[slot];
+    if(sl.pending) return fail(h, MSK144_ESTATE, "slot already has a fetch in flight");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    long long guess = 2ll * h->last_total.load(std::memory_order_relaxed) + 256;
+    if(guess < 1024) guess = 1024;
+    if(guess > h->st.max_results) guess = h->st.max_results;
+    sl.copied = static_cast<int32_t>(guess);
+    ev_begin(h, MSK144_T_D2H);
+    hipError_t e = hipMemcpyAsync(sl.out_count, h->st.result_count, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if(e == hipSuccess) e = hipMemcpyAsync(sl.out_seg, h->st.seg_power, sizeof(float) * 8 * h->st.channels, hipMemcpyDeviceToHost, h->stream);
+    if(e == hipSuccess) e = hipMemcpyAsync(sl.out, sl.d_records, sizeof(msk144_result) * static_cast<size_t>(sl.copied), hipMemcpyDeviceToHost, h->stream);
+    ev_end(h, MSK144_T_D2H);
+    if(e == hipSuccess) e = hipEventRecord(sl.done, h->stream);
+    if(e != hipSuccess) return fail(h, MSK144_EHIP, std::string("msk144_fetch_async: ") + hipGetErrorString(e));
+    sl.pending = true;
+    return MSK144_OK;
+}
+
+// May run on a second thread (the other slot being submitted meanwhile): touches only this slot, last_total and copy_stream.
+int msk144_fetch_wait(msk144_handle* h, int32_t slot, const msk144_result** records, int32_t* n, const float** seg_power)
+{
+    if(!h || !records || !n || slot < 0 || slot >= MSK144_SLOTS) return MSK144_EINVAL;
+    msk144_handle::Slot& sl = h->slots[slot];
+    if(!h->slots_ready || !sl.pending) return MSK144_ESTATE;
+    if(hipSetDevice(h->params.device) != hipSuccess || hipEventSynchronize(sl.done) != hipSuccess) return MSK144_EHIP;
+    const int32_t total = *sl.out_count;
+    const int32_t avail = total < h->st.max_results ? total : h->st.max_results;
+    if(avail > sl.copied)
+    {
+        // the estimate was short: the slot's own device list is still intact (the other slot decodes into its own)
+        hipError_t e = hipMemcpyAsync(sl.out + sl.copied, sl.d_records + sl.copied, sizeof(msk144_result) * static_cast<size_t>(avail - sl.copied), hipMemcpyDeviceToHost,
+                                      h->copy_stream);
+        if(e == hipSuccess) e = hipStreamSynchronize(h->copy_stream);
+        if(e != hipSuccess) return MSK144_EHIP;
+    }
+    h->last_total.store(total, std::memory_order_relaxed);
+    sl.pending = false;
+    *records = sl.out;
+    *n = avail;
+    if(seg_power) *seg_power = sl.out_seg;
+    return total > h->st.max_results ? MSK144_EOVERFLOW : MSK144_OK;
 }
 
 int msk144_dump_analytic(msk144_handle* h, int32_t channel, float* out)

@@ -18,7 +18,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmsk144hip.so")
 
 STAGE_SCAN, STAGE_SOFTBITS, STAGE_INDEX, STAGE_LDPC, STAGE_COLLECT, STAGE_ALL = 1, 2, 4, 8, 16, 31
-T_NAMES = ("frontend", "scan", "softbits", "index", "ldpc", "collect")
+T_NAMES = ("frontend", "scan", "softbits", "index", "ldpc", "collect", "h2d", "d2h")
 
 # every symbol include/msk144hip.h declares (tests check the library exports each of them)
 ABI_SYMBOLS = (
@@ -27,6 +27,7 @@ ABI_SYMBOLS = (
     "msk144_submit_analytic", "msk144_decode", "msk144_decode_stages", "msk144_synchronize", "msk144_results",
     "msk144_result_count", "msk144_results_device", "msk144_set_channel_base", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
+    "msk144_input_slot", "msk144_submit_slot", "msk144_fetch_async", "msk144_fetch_wait",
 )
 
 
@@ -100,6 +101,10 @@ def load_library(path: Optional[str] = None):
     L.msk144_load_candidates.argtypes = [vp, i32, vp]
     L.msk144_set_profiling.argtypes = [vp, i32]
     L.msk144_stage_times.argtypes = [vp, vp, vp, i32]
+    L.msk144_input_slot.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.msk144_submit_slot.argtypes = [vp, i32]
+    L.msk144_fetch_async.argtypes = [vp, i32]
+    L.msk144_fetch_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp)]
     if path is None:
         _lib = L
     return L
@@ -214,6 +219,29 @@ class HipDecoder:
         out = np.empty((self.channels, 8), dtype=np.float32)
         self._chk(self.L.msk144_segment_power(self.h, _ptr(out)))
         return out
+
+    # ---- pinned staging slots (pipelined hops) ----
+    def input_slot(self, slot: int) -> np.ndarray:
+        """The slot's pinned window buffer as a numpy view: int16 [channels][5184] or int8 [channels][2*5184]."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.msk144_input_slot(self.h, slot, C.byref(ptr), C.byref(nbytes)))
+        raw = (C.c_uint8 * nbytes.value).from_address(ptr.value)
+        a = np.frombuffer(raw, dtype=np.int8 if self.read_mode == 2 else np.int16)
+        return a.reshape(self.channels, -1)
+
+    def submit_slot(self, slot: int):
+        self._chk(self.L.msk144_submit_slot(self.h, slot))
+
+    def fetch_async(self, slot: int):
+        self._chk(self.L.msk144_fetch_async(self.h, slot))
+
+    def fetch_wait(self, slot: int):
+        """(records, segment powers [channels][8]) of the slot, copied out of its pinned output."""
+        rec, seg, n = C.c_void_p(), C.c_void_p(), C.c_int32()
+        self._chk(self.L.msk144_fetch_wait(self.h, slot, C.byref(rec), C.byref(n), C.byref(seg)))
+        records = np.frombuffer((C.c_uint8 * (n.value * RESULT_DTYPE.itemsize)).from_address(rec.value), dtype=RESULT_DTYPE).copy() if n.value else np.zeros(0, dtype=RESULT_DTYPE)
+        powers = np.frombuffer((C.c_float * (8 * self.channels)).from_address(seg.value), dtype=np.float32).reshape(self.channels, 8).copy()
+        return records, powers
 
     # ---- parity / debug ----
     def dump_analytic(self, channel=0) -> np.ndarray:

@@ -2,21 +2,30 @@
 // Same command-line options, input framing, help text, stderr parameter block and output lines as the reference program
 // (main.cu:55-426), with the GPU work behind libmsk144hip.so.  Beyond the reference: several raw
 // streams (files or FIFOs) decoded as ONE GPU batch per hop, read without blocking so that a stalled stream never holds
-// the others back, with per-stream hop-deadline accounting (the reference's 210 ms watchdog, per batch and per stream).
+// the others back, with per-stream hop-deadline accounting (the reference's 210 ms watchdog, per batch and per stream).  The
+// multi-stream loop is pipelined over the library's two pinned staging slots: this thread reads the streams and submits hop n+1
+// while the GPU decodes hop n and a second thread turns the records of hop n-1 into text.
 #include "window_decoder.h"
 
 #include <fcntl.h>
 #include <getopt.h>
 #include <poll.h>
+#include <sys/resource.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <fstream>
 #include <iostream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace msk144host;
@@ -43,12 +52,14 @@ void show_help(const char* prog)
     std::cout << "                   --nbadsync-threshold=[1..4] Specifies how many errors in sync pattern are acceptable to be passed to LDPC decoder. Default=2." << std::endl;
     std::cout << " Additions of msk144hipdecoder (defaults in effect, as in the reference's code: search-width 200, scan-depth 4, nbadsync-threshold 1):" << std::endl;
     std::cout << "                   --inputs=F1,F2,...          Decode several raw streams (files or FIFOs) as one GPU batch per hop instead of stdin; lines then carry ch=<index>." << std::endl;
+    std::cout << "                   --inputs-file=PATH          The same, one stream path per line (for hundreds of streams)." << std::endl;
     std::cout << "                   --hop-timeout-ms=N          With --inputs: how long a batch waits for lagging streams once the first one has a hop ready. Default=216 (one hop)." << std::endl;
     std::cout << "                   --skip-wav-header           Drop the first 44 bytes of every stream (the reference decodes a RIFF header as 22 samples). Default off." << std::endl;
     std::cout << "                   --reference-decode-cache    Reproduce the reference's per-window text cache, whose comparator is always false: every decode of a window prints the text of the first one. Default: each distinct payload gets its own text." << std::endl;
     std::cout << "                   --strict-decode             Accepted for compatibility (this is the default now)." << std::endl;
     std::cout << "                   --print-bits                Append the 77-bit payload to each output line." << std::endl;
     std::cout << "                   --device=N                  HIP device ordinal. Default=0." << std::endl;
+    std::cout << "                   --timing                    With --inputs: per-hop host and device time split (ingest, H2D, GPU, D2H, post-processing) on stderr at the end." << std::endl;
     // clang-format on
 }
 
@@ -111,10 +122,39 @@ struct Stream
     std::vector<unsigned char> pending;
     bool ready = false;           // a complete hop sits in `pending`
     Clock::time_point ready_at;
-    // deadline accounting
+    int last_slot = -1;           // staging slot that holds this stream's latest window
+    // deadline accounting (owned by the post-processing thread)
     long hops = 0, late = 0;
     long long worst_ms = 0;
 };
+
+// One submitted hop of every ready stream, handed from the ingest thread to the post-processing thread.
+struct Batch
+{
+    int slot = 0;
+    std::vector<bool> active;
+    std::vector<Clock::time_point> ready_at;  // per stream, meaningful where active
+    Clock::time_point go;                      // batch released by the policy
+    double assemble_ms = 0.0, submit_ms = 0.0;
+};
+
+struct Accumulator
+{
+    double sum = 0.0, worst = 0.0;
+    long n = 0;
+    void add(double v)
+    {
+        sum += v;
+        worst = std::max(worst, v);
+        n++;
+    }
+    double mean() const { return n ? sum / n : 0.0; }
+};
+
+double ms_between(Clock::time_point a, Clock::time_point b)
+{
+    return std::chrono::duration<double, std::milli>(b - a).count();
+}
 
 }  // namespace
 
@@ -124,6 +164,7 @@ int main(int argc, char* const argv[])
     bool center_set = false;
     bool skip_wav = false;
     int hop_timeout_ms = 216;
+    bool timing = false;
     std::vector<std::string> input_paths;
 
     static struct option long_options[] = {{"help", no_argument, 0, 0},
@@ -141,6 +182,8 @@ int main(int argc, char* const argv[])
                                            {"reference-decode-cache", no_argument, 0, 0},
                                            {"skip-wav-header", no_argument, 0, 0},
                                            {"hop-timeout-ms", required_argument, 0, 0},
+                                           {"inputs-file", required_argument, 0, 0},
+                                           {"timing", no_argument, 0, 0},
                                            {0, 0, 0, 0}};
     while(true)
     {
@@ -165,6 +208,19 @@ int main(int argc, char* const argv[])
         case 12: opt.reference_cache_quirk = true; break;
         case 13: skip_wav = true; break;
         case 14: hop_timeout_ms = atoi(optarg); break;
+        case 15:
+        {
+            std::ifstream f(optarg);
+            if(!f)
+            {
+                std::cerr << "Cannot open input list " << optarg << std::endl;
+                return 2;
+            }
+            for(std::string line; std::getline(f, line);)
+                if(!line.empty()) input_paths.push_back(line);
+            break;
+        }
+        case 16: timing = true; break;
         default: show_help(argv[0]); return 0;
         }
     }
@@ -189,6 +245,17 @@ int main(int argc, char* const argv[])
 
     const int nch = input_paths.empty() ? 1 : static_cast<int>(input_paths.size());
     opt.channels = nch;
+    opt.profile = timing && !input_paths.empty();
+    {
+        // one descriptor per stream plus what the runtime opens: lift the soft limit when the hard limit allows
+        rlimit lim{};
+        const rlim_t want = static_cast<rlim_t>(nch) + 256;
+        if(getrlimit(RLIMIT_NOFILE, &lim) == 0 && lim.rlim_cur < want)
+        {
+            lim.rlim_cur = (lim.rlim_max == RLIM_INFINITY || lim.rlim_max > want) ? want : lim.rlim_max;
+            setrlimit(RLIMIT_NOFILE, &lim);
+        }
+    }
 
     WindowDecoder dec(opt);
     if(!dec.ok())
@@ -224,7 +291,6 @@ int main(int argc, char* const argv[])
     const size_t win_bytes = MSK144_WINDOW_SAMPLES * sample_bytes;
     const size_t half = win_bytes / 2;
     const size_t unit = (opt.read_mode == 1) ? sizeof(int16_t) : sizeof(int8_t);  // the reference counts items of this size
-    std::vector<unsigned char> ring(win_bytes * nch, 0);
     std::vector<std::vector<FilteredResult>> lines;
 
     if(input_paths.empty())
@@ -235,6 +301,7 @@ int main(int argc, char* const argv[])
             unsigned char hdr[44];
             if(fread(hdr, 1, sizeof(hdr), stdin) != sizeof(hdr)) std::cerr << "Incomplete read error. rc=0" << std::endl;
         }
+        std::vector<unsigned char> ring(win_bytes, 0);
         bool first = true;
         const std::vector<bool> active(1, true);
         while(true)
@@ -271,7 +338,7 @@ int main(int argc, char* const argv[])
         return 0;
     }
 
-    // ---- several streams, one GPU batch per hop, non-blocking ingest ----
+    // ---- several streams, one GPU batch per hop, non-blocking ingest, pipelined over two staging slots ----
     std::vector<Stream> st(nch);
     for(int c = 0; c < nch; c++)
     {
@@ -279,25 +346,118 @@ int main(int argc, char* const argv[])
         st[c].fd = open(input_paths[c].c_str(), O_RDONLY | O_NONBLOCK);
         if(st[c].fd < 0)
         {
-            std::cerr << "Cannot open input " << input_paths[c] << std::endl;
+            std::cerr << "Cannot open input " << input_paths[c] << ": " << strerror(errno) << std::endl;
             return 2;
         }
         st[c].skip = skip_wav ? 44 : 0;
         st[c].pending.reserve(win_bytes);
     }
-    std::vector<pollfd> pfd(nch);
-    std::vector<bool> active(nch, false);
-    std::vector<unsigned char> chunk(1 << 16);
+    unsigned char* stage[WindowDecoder::kSlots];
+    for(int k = 0; k < WindowDecoder::kSlots; k++)
+    {
+        stage[k] = static_cast<unsigned char*>(dec.stage(k));  // pinned, owned by the library handle
+        if(!stage[k])
+        {
+            std::cerr << "msk144hip: " << dec.error() << std::endl;
+            return 2;
+        }
+        memset(stage[k], 0, win_bytes * nch);
+    }
+
+    // hand-over between this (ingest + submit) thread and the post-processing thread
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Batch> in_flight;
+    std::deque<int> free_slots;
+    for(int k = 0; k < WindowDecoder::kSlots; k++) free_slots.push_back(k);
+    bool no_more = false, failed = false;
+    Accumulator t_assemble, t_submit, t_wait, t_post, t_print, t_latency, t_records;
     long batches = 0;
+
+    std::thread post([&]() {
+        std::vector<std::vector<FilteredResult>> out;
+        while(true)
+        {
+            Batch b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !in_flight.empty() || no_more; });
+                if(in_flight.empty()) return;
+                b = std::move(in_flight.front());
+                in_flight.pop_front();
+            }
+            HopTiming ht;
+            if(!dec.collect(b.slot, out, &ht))
+            {
+                std::cerr << "msk144hip: " << dec.error() << std::endl;
+                std::lock_guard<std::mutex> lk(mu);
+                failed = true;
+                cv.notify_all();
+                return;
+            }
+            const auto p0 = Clock::now();
+            print_lines(nch, out);
+            const auto p1 = Clock::now();
+            warn_if_late(std::chrono::duration_cast<std::chrono::milliseconds>(p1 - b.go).count());
+            // per-stream deadline: from "hop complete" to "lines printed" a stream has one hop period (216 ms) before its next
+            // hop is due; the reference's soft limit of 210 ms (main.cu:398-403) is applied per stream
+            for(int c = 0; c < nch; c++)
+            {
+                if(!b.active[c]) continue;
+                Stream& s = st[c];
+                const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(p1 - b.ready_at[c]).count();
+                s.hops++;
+                if(ms > 210) s.late++;
+                if(ms > s.worst_ms) s.worst_ms = ms;
+            }
+            t_assemble.add(b.assemble_ms);
+            t_submit.add(b.submit_ms);
+            t_wait.add(ht.wait_ms);
+            t_post.add(ht.post_ms);
+            t_print.add(ms_between(p0, p1));
+            t_latency.add(ms_between(b.go, p1));
+            t_records.add(ht.records);
+            batches++;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                free_slots.push_back(b.slot);
+            }
+            cv.notify_all();
+        }
+    });
+    auto finish = [&](int code) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            no_more = true;
+        }
+        cv.notify_all();
+        post.join();
+        return code;
+    };
+
+    std::vector<pollfd> pfd(nch);
+    std::vector<unsigned char> chunk(1 << 16);
+    Accumulator t_ingest;
+    auto ingest_since = Clock::now();
+    double ingest_busy_ms = 0.0;
 
     while(true)
     {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if(failed) break;
+        }
         // 1. drain whatever every open stream has, up to one hop each
+        const auto d0 = Clock::now();
         int open_streams = 0, ready = 0;
         for(int c = 0; c < nch; c++)
         {
             Stream& s = st[c];
-            if(s.eof) continue;
+            if(s.eof)
+            {
+                if(s.ready) ready++;
+                continue;
+            }
             open_streams++;
             const size_t need = s.first ? win_bytes : half;
             while(!s.ready)
@@ -332,10 +492,11 @@ int main(int argc, char* const argv[])
             }
             if(s.ready) ready++;
         }
+        ingest_busy_ms += ms_between(d0, Clock::now());
         if(open_streams == 0 && ready == 0) break;
 
         // 2. batch policy: go when every open stream has its hop, or when the oldest ready hop has waited hop_timeout_ms
-        bool go = ready > 0 && ready == open_streams;
+        bool go = ready > 0 && ready >= open_streams;
         if(!go && ready > 0)
         {
             Clock::time_point oldest = Clock::now();
@@ -352,45 +513,58 @@ int main(int argc, char* const argv[])
             continue;
         }
 
-        // 3. advance the window ring of the streams that have a hop; the others keep their state and sit this batch out
+        // 3. a free staging slot (back-pressure: with both slots in flight the streams wait in their pipes)
+        Batch b;
+        b.go = Clock::now();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !free_slots.empty() || failed; });
+            if(failed) break;
+            b.slot = free_slots.front();
+            free_slots.pop_front();
+        }
+        // 4. advance the window of the streams that have a hop, straight into the pinned slot: first half = second half of the
+        // stream's latest window (in this slot or the other one), second half = the new hop; the others sit this batch out
+        const auto a0 = Clock::now();
+        b.active.assign(nch, false);
+        b.ready_at.assign(nch, a0);
         for(int c = 0; c < nch; c++)
         {
             Stream& s = st[c];
-            active[c] = s.ready;
             if(!s.ready) continue;
-            unsigned char* w = ring.data() + win_bytes * c;
+            b.active[c] = true;
+            b.ready_at[c] = s.ready_at;
+            unsigned char* w = stage[b.slot] + win_bytes * c;
             if(s.first) memcpy(w, s.pending.data(), win_bytes);
             else
             {
-                memcpy(w, w + half, half);
+                if(s.last_slot == b.slot) memmove(w, w + half, half);
+                else memcpy(w, stage[s.last_slot] + win_bytes * c + half, half);
                 memcpy(w + half, s.pending.data(), half);
             }
             s.first = false;
+            s.last_slot = b.slot;
             s.pending.clear();
-        }
-        const auto t0 = Clock::now();
-        if(!dec.process(ring.data(), active, lines))
-        {
-            std::cerr << "msk144hip: " << dec.error() << std::endl;
-            return 2;
-        }
-        print_lines(nch, lines);
-        const auto t1 = Clock::now();
-        warn_if_late(std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
-        batches++;
-        // per-stream deadline: from "hop complete" to "lines printed" a stream has one hop period (216 ms) before its next
-        // hop is due; the reference's soft limit of 210 ms is applied per stream
-        for(int c = 0; c < nch; c++)
-        {
-            Stream& s = st[c];
-            if(!s.ready) continue;
-            const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(t1 - s.ready_at).count();
-            s.hops++;
-            if(ms > 210) s.late++;
-            if(ms > s.worst_ms) s.worst_ms = ms;
             s.ready = false;
         }
+        const auto a1 = Clock::now();
+        if(!dec.submit(b.slot, b.active))
+        {
+            std::cerr << "msk144hip: " << dec.error() << std::endl;
+            return finish(2);
+        }
+        b.assemble_ms = ms_between(a0, a1);
+        b.submit_ms = ms_between(a1, Clock::now());
+        t_ingest.add(ingest_busy_ms);
+        ingest_busy_ms = 0.0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            in_flight.push_back(std::move(b));
+        }
+        cv.notify_all();
     }
+    finish(0);
+    if(failed) return 2;
 
     long total_hops = 0, total_late = 0;
     long long worst = 0;
@@ -403,6 +577,26 @@ int main(int argc, char* const argv[])
         close(st[c].fd);
     }
     std::cerr << "msk144hipdecoder: " << batches << " batches, " << total_hops << " stream hops, " << total_late << " late, worst latency " << worst << " ms" << std::endl;
+    if(timing)
+    {
+        const double wall_s = ms_between(ingest_since, Clock::now()) * 1e-3;
+        auto row = [](const char* name, const Accumulator& a) {
+            fprintf(stderr, "msk144hipdecoder timing: %-34s mean %9.3f ms  max %9.3f ms\n", name, a.mean(), a.worst);
+        };
+        fprintf(stderr, "msk144hipdecoder timing: %d streams, %ld batches in %.2f s wall; per batch (host wall time):\n", nch, batches, wall_s);
+        row("ingest (read syscalls, all streams)", t_ingest);
+        row("assemble windows in pinned slot", t_assemble);
+        row("submit (3 asynchronous calls)", t_submit);
+        row("wait for GPU + D2H (post thread)", t_wait);
+        row("post-processing (text, SNR, filter)", t_post);
+        row("print", t_print);
+        row("batch released -> lines printed", t_latency);
+        fprintf(stderr, "msk144hipdecoder timing: records per batch mean %.0f max %.0f\n", t_records.mean(), t_records.worst);
+        float dev[MSK144_T_COUNT];
+        if(dec.stage_times(dev))
+            fprintf(stderr, "msk144hipdecoder timing: device per batch (HIP events): H2D %.3f  front end %.3f  scan %.3f  softbits %.3f  index %.3f  LDPC %.3f  collect %.3f  D2H %.3f ms\n",
+                    dev[MSK144_T_H2D], dev[MSK144_T_FRONTEND], dev[MSK144_T_SCAN], dev[MSK144_T_SOFTBITS], dev[MSK144_T_INDEX], dev[MSK144_T_LDPC], dev[MSK144_T_COLLECT], dev[MSK144_T_D2H]);
+    }
     std::cout << "Done" << std::endl;
     return 0;
 }

@@ -1,5 +1,8 @@
 #include "window_decoder.h"
 
+#include <chrono>
+#include <cstring>
+
 namespace msk144host
 {
 
@@ -18,7 +21,11 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
     p.channels = opt.channels < 1 ? 1 : opt.channels;
     opt_.channels = p.channels;
     p.device = opt.device;
-    p.max_results = 0x7fffffff;  // clamped by the library to channels * items: the list can never overflow
+    // Compact-list capacity: a strong ping is accepted by many of its candidates (neighbouring bins, patterns, slots), 256 per
+    // channel on average is far beyond anything a real band produces; the library clamps to channels * items, and a list that did
+    // overflow is an error (MSK144_EOVERFLOW), never a silent truncation.
+    const long long cap = 256ll * p.channels + 4096;
+    p.max_results = cap > 0x7fffffff ? 0x7fffffff : static_cast<int32_t>(cap);
     if(msk144_create(&p, &handle_) != MSK144_OK)
     {
         error_ = msk144_last_error(nullptr);
@@ -29,7 +36,8 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
     snr_.resize(opt_.channels);
     filter_.resize(opt_.channels);
     calls_.resize(opt_.channels);
-    seg_.resize(static_cast<size_t>(opt_.channels) * 8);
+    window_bytes_ = static_cast<size_t>(opt_.channels) * MSK144_WINDOW_SAMPLES * (opt_.read_mode == 2 ? 2 * sizeof(int8_t) : sizeof(int16_t));
+    if(opt_.profile) msk144_set_profiling(handle_, 1);
 }
 
 WindowDecoder::~WindowDecoder()
@@ -61,34 +69,69 @@ bool WindowDecoder::process(const void* window, std::vector<FilteredResult>& lin
 
 bool WindowDecoder::process(const void* windows, const std::vector<bool>& active, std::vector<std::vector<FilteredResult>>& lines)
 {
-    const int nch = opt_.channels;
-    lines.assign(nch, {});
-    int rc = (opt_.read_mode == 2) ? msk144_submit_iq(handle_, static_cast<const int8_t*>(windows))
-                                   : msk144_submit_audio(handle_, static_cast<const int16_t*>(windows));
-    if(rc == MSK144_OK) rc = msk144_decode(handle_);
-    if(rc == MSK144_OK) rc = msk144_segment_power(handle_, seg_.data());
-    int32_t n = 0;
-    if(rc == MSK144_OK) rc = msk144_result_count(handle_, &n);
-    if(rc == MSK144_OK)
+    void* in = stage(0);
+    if(!in) return false;
+    if(windows != in) std::memcpy(in, windows, window_bytes_);
+    return submit(0, active) && collect(0, lines);
+}
+
+void* WindowDecoder::stage(int slot)
+{
+    void* p = nullptr;
+    if(msk144_input_slot(handle_, slot, &p, nullptr) != MSK144_OK)
     {
-        results_.resize(n > 0 ? n : 1);
-        rc = msk144_results(handle_, results_.data(), static_cast<int32_t>(results_.size()), &n);
-        results_.resize(n);
+        error_ = msk144_last_error(handle_);
+        return nullptr;
     }
+    return p;
+}
+
+bool WindowDecoder::submit(int slot, const std::vector<bool>& active)
+{
+    active_[slot] = active;
+    int rc = msk144_submit_slot(handle_, slot);
+    if(rc == MSK144_OK) rc = msk144_decode(handle_);
+    if(rc == MSK144_OK) rc = msk144_fetch_async(handle_, slot);
     if(rc != MSK144_OK)
     {
         error_ = msk144_last_error(handle_);
         return false;
     }
+    return true;
+}
+
+bool WindowDecoder::stage_times(float out[MSK144_T_COUNT])
+{
+    return msk144_stage_times(handle_, out, nullptr, 0) == MSK144_OK;
+}
+
+bool WindowDecoder::collect(int slot, std::vector<std::vector<FilteredResult>>& lines, HopTiming* timing)
+{
+    using Clock = std::chrono::steady_clock;
+    const int nch = opt_.channels;
+    lines.assign(nch, {});
+    const auto t0 = Clock::now();
+    const msk144_result* results = nullptr;
+    const float* seg = nullptr;
+    int32_t n = 0;
+    const int rc = msk144_fetch_wait(handle_, slot, &results, &n, &seg);
+    if(rc != MSK144_OK)
+    {
+        error_ = rc == MSK144_EOVERFLOW ? "more decodes in one hop than the compact result list holds" : "msk144_fetch_wait failed";
+        return false;
+    }
+    const auto t1 = Clock::now();
+    const std::vector<bool>& active = active_[slot];
+    const size_t n_results = static_cast<size_t>(n);
 
     // results arrive ordered by (channel, item): walk them channel by channel
     size_t r = 0;
     for(int c = 0; c < nch; c++)
     {
         std::vector<AcceptedCandidate> accepted;
-        for(; r < results_.size() && results_[r].channel == c; r++)
+        for(; r < n_results && results[r].channel == c; r++)
         {
-            const msk144_result& res = results_[r];
+            const msk144_result& res = results[r];
             AcceptedCandidate a;
             a.f0 = res.f0;
             a.num_avg = res.num_avg;
@@ -98,7 +141,7 @@ bool WindowDecoder::process(const void* windows, const std::vector<bool>& active
             accepted.push_back(a);
         }
         if(c < static_cast<int>(active.size()) && !active[c]) continue;  // ended stream: leave its state alone
-        snr_[c].update(&seg_[static_cast<size_t>(c) * 8]);  // main.cu:388
+        snr_[c].update(&seg[static_cast<size_t>(c) * 8]);  // main.cu:388
         lines[c] = postprocess_window(accepted, snr_[c].snr_int(), opt_.reference_cache_quirk, calls_[c], filter_[c]);
         if(opt_.print_bits)
         {
@@ -119,6 +162,12 @@ bool WindowDecoder::process(const void* windows, const std::vector<bool>& active
                 }
             }
         }
+    }
+    if(timing)
+    {
+        timing->wait_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        timing->post_ms = std::chrono::duration<double, std::milli>(Clock::now() - t1).count();
+        timing->records = n;
     }
     return true;
 }

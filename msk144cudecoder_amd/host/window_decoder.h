@@ -33,6 +33,15 @@ struct DecoderOptions
     // (--reference-decode-cache): reproduce the reference, for byte-for-byte stdout parity on inputs where it matters.
     bool reference_cache_quirk = false;
     bool print_bits = false;  // append the 77-bit payload to each line (debug)
+    bool profile = false;     // record per-stage device times (HIP events; --timing)
+};
+
+// Host wall time of one hop, split the way the pipelined loop spends it.
+struct HopTiming
+{
+    double wait_ms = 0.0;  // blocked until the GPU had finished the hop and its results had arrived (msk144_fetch_wait)
+    double post_ms = 0.0;  // payload -> text, SNR, per-window filter
+    int records = 0;
 };
 
 // What one accepted candidate contributes, independent of the GPU (unit-testable on the CPU).
@@ -77,6 +86,18 @@ public:
     // single-stream convenience (channels == 1)
     bool process(const void* window, std::vector<FilteredResult>& lines);
 
+    // The same hop in pipelined form, over the two pinned staging slots the library handle owns: fill stage(slot), submit it
+    // (asynchronous: H2D, front end, decode, D2H of count + records + segment powers), and collect it later - possibly on a
+    // second thread while the other slot is being filled and submitted.  The reference's loop is strictly serial per hop
+    // (main.cu:261-422).
+    static constexpr int kSlots = MSK144_SLOTS;
+    void* stage(int slot);
+    bool submit(int slot, const std::vector<bool>& active);
+    bool collect(int slot, std::vector<std::vector<FilteredResult>>& lines, HopTiming* timing = nullptr);
+    // average device milliseconds per hop of every stage (frontend, scan, softbits, index, ldpc, collect, h2d, d2h); needs
+    // DecoderOptions::profile; waits for the GPU
+    bool stage_times(float out[MSK144_T_COUNT]);
+
 private:
     DecoderOptions opt_;
     msk144_handle* handle_ = nullptr;
@@ -86,8 +107,8 @@ private:
     std::vector<SnrTracker> snr_;
     std::vector<ResultFilter> filter_;
     std::vector<CallHashTable> calls_;
-    std::vector<msk144_result> results_;
-    std::vector<float> seg_;
+    std::vector<bool> active_[kSlots];
+    size_t window_bytes_ = 0;  // per batch
 };
 
 }  // namespace msk144host

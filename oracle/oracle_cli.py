@@ -42,8 +42,10 @@ def windows_of(stream: np.ndarray, read_mode: int):
         s += hop
 
 
-def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, quirk: bool = False, threads: int = 8, mask_date: bool = True):
-    """All output lines (without the final 'Done') the reference program would print for `stream`."""
+def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, quirk: bool = False, threads: int = 8, mask_date: bool = True,
+                  payloads: set = None):
+    """All output lines (without the final 'Done') the reference program would print for `stream`.  `payloads`, when given, collects
+    the 77-bit payload (as a '0'/'1' string) of every accepted candidate of every window - the text-independent artefact."""
     H = C.CDLL(HOST_SO)
     H.msk144host_table_new.restype = C.c_void_p
     H.msk144host_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
@@ -56,6 +58,8 @@ def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_me
         s = snr.process(cd)
         items, _ = o.decode_window(cd)
         acc = items[items["is_message_present"] == 1]
+        if payloads is not None:
+            payloads.update("".join(str(int(b)) for b in it["message"]) for it in acc)
         arr = (Accepted * max(len(acc), 1))()
         for a, it in zip(arr, acc):
             a.f0, a.num_avg, a.nbadsync, a.pattern_idx = float(it["f0"]), int(it["num_avg"]), int(it["nbadsync"]), int(it["pattern_idx"])

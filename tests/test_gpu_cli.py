@@ -124,6 +124,30 @@ def test_cli_s1_stream_light_config(orc):
     assert "Left Boundary: 1450Hz" in err and "Right Boundary: 1550Hz" in err
 
 
+def test_cli_s1_stream_deep_config(orc):
+    """BASELINE configs[1] stand-in (demo/0001.wav is absent): an S1 stream through stdin -> stdout at the deep options of
+    README.md:65-67 (--search-width=500 --search-step=1 --scan-depth=6 --nbadsync-threshold=3: F=501, 24 048 candidates per window)
+    - window ring, GPU path, SNR tracker, text layer and per-window filter - line for line against the oracle-driven CPU decoder
+    (main.cu:261-422), and, independent of the text layer, the printed 77-bit payloads against the oracle's accepted payloads."""
+    from oracle import oracle_cli
+    stream, pings = synth.stream_s1(1, seconds=3.5, n_pings=3, span=240.0)
+    cfg = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
+    args = ["--search-width=500", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=3"]
+    rc, out, err = _run(args, stream.tobytes())
+    assert rc == 0, err
+    assert "Left Boundary: 1250Hz" in err and "Right Boundary: 1750Hz" in err and "Softbit-kernel CUDA blocks: 501*48=24048" in err
+    got = [re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]]
+    accepted = set()
+    want = oracle_cli.decode_stream(stream, cfg, 1, 2, quirk=False, threads=16, payloads=accepted)
+    assert got == want and len(want) >= 2
+    rc, out, err = _run(args + ["--print-bits"], stream.tobytes())
+    assert rc == 0, err
+    printed = set(re.findall(r"bits='([01]{77})'", out))
+    sent = {"".join(str(int(b)) for b in p.msg77) for p in pings}
+    assert printed and printed <= accepted            # every printed payload is one the oracle accepted
+    assert printed & sent == accepted & sent and printed & sent   # and every transmitted payload the oracle decodes is printed
+
+
 def test_stderr_parameter_block_is_the_references():
     """main.cu:233-252: same labels, same order, values the reference would print for these options (F = 11, depth 3)."""
     import json

@@ -60,7 +60,6 @@ def test_1024_channel_batch_properties(orc, hip, parity_report):
     # the PRODUCTION path - default blocked staging (64-channel blocks, softbits_kernel<true>: gated-out candidates stop after
     # their sync check), what bench.py times - must give the retained-mode list byte for byte at full size
     with hip.HipDecoder(channels=1024, max_results=1 << 20, **DEEP) as dp:
-        assert dp.params.llr_block_channels == 64
         dp.submit_audio(wins[2])
         dp.decode()
         prod = dp.results().copy()
@@ -142,7 +141,6 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
     assert res1.tobytes() == res2.tobytes()                             # deterministic
     # production path (default 64-channel blocks, gated softbits) at full size: same list, byte for byte
     with hip.HipDecoder(read_mode=2, channels=nch, max_results=1 << 20, **cfg) as dp:
-        assert dp.params.llr_block_channels == 64
         dp.submit_iq(wins)
         dp.decode()
         prod = dp.results().copy()

@@ -1,0 +1,160 @@
+"""-m gpu: the pinned staging slots of the C ABI (msk144_input_slot .. msk144_fetch_wait, include/msk144hip.h) - the pipelined form
+of the reference's per-hop sequence fread -> H2D -> kernels -> D2H -> host loop (main.cu:261-422, 474-525).  A hop decoded through
+a slot must return exactly what the serial calls return, whatever is in flight on the other slot."""
+import threading
+
+import numpy as np
+import pytest
+
+from msk144cudecoder_amd import synth
+
+pytestmark = pytest.mark.gpu
+CFG = dict(center=1500.0, width=60.0, step=1.0, depth=6, nbadsync_threshold=3)
+
+
+def _windows(n_hops, channels, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_hops):
+        w = np.empty((channels, 5184), dtype=np.int16)
+        for c in range(channels):
+            pings = [synth.Ping(synth.random_message(rng), int(rng.integers(0, 2000)), int(rng.integers(2, 6)), 1500.0 + float(rng.uniform(-25, 25)), 3.0,
+                                float(rng.uniform(0, 6)))] if c % 2 == 0 else []
+            w[c] = synth.synth_audio(5184, pings, 1000.0, rng)
+        out.append(w)
+    return out
+
+
+def _serial(hip, wins, channels, **kw):
+    ref = []
+    with hip.HipDecoder(channels=channels, max_results=1 << 16, **CFG, **kw) as d:
+        for w in wins:
+            d.submit_audio(w)
+            d.decode()
+            ref.append((d.results().copy(), d.segment_power().copy()))
+    return ref
+
+
+def test_pipelined_slots_equal_serial_calls(hip):
+    channels, hops = 12, 6
+    wins = _windows(hops, channels, 11)
+    ref = _serial(hip, wins, channels)
+    assert sum(len(r) for r, _ in ref) > 20
+    with hip.HipDecoder(channels=channels, max_results=1 << 16, **CFG) as d:
+        got = []
+        # software pipeline: hop n is submitted before hop n-1 is fetched, so both slots are in flight at once
+        for n, w in enumerate(wins):
+            s = n % 2
+            d.input_slot(s)[:] = w
+            d.submit_slot(s)
+            d.decode()
+            d.fetch_async(s)
+            if n >= 1:
+                got.append(d.fetch_wait(1 - s))
+        got.append(d.fetch_wait((hops - 1) % 2))
+    for (r0, p0), (r1, p1) in zip(ref, got):
+        assert r0.tobytes() == r1.tobytes()
+        assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+
+
+def test_fetch_wait_on_a_second_thread(hip):
+    """The post-processing thread of msk144hipdecoder waits for slot s while the ingest thread submits slot 1 - s."""
+    channels, hops = 8, 8
+    wins = _windows(hops, channels, 12)
+    ref = _serial(hip, wins, channels)
+    got, errors = [None] * hops, []
+    with hip.HipDecoder(channels=channels, max_results=1 << 16, **CFG) as d:
+        free = [threading.Semaphore(1), threading.Semaphore(1)]
+        queue, cond = [], threading.Condition()
+
+        def consumer():
+            try:
+                for n in range(hops):
+                    with cond:
+                        cond.wait_for(lambda: queue)
+                        k = queue.pop(0)
+                    got[k] = d.fetch_wait(k % 2)
+                    free[k % 2].release()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                for f in free:
+                    f.release()
+
+        t = threading.Thread(target=consumer)
+        t.start()
+        for n, w in enumerate(wins):
+            s = n % 2
+            free[s].acquire()
+            if errors:
+                break
+            d.input_slot(s)[:] = w
+            d.submit_slot(s)
+            d.decode()
+            d.fetch_async(s)
+            with cond:
+                queue.append(n)
+                cond.notify()
+        t.join(timeout=120)
+        assert not t.is_alive() and not errors, errors
+    for (r0, p0), (r1, p1) in zip(ref, got):
+        assert r0.tobytes() == r1.tobytes() and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+
+
+def test_short_estimate_takes_the_remainder_copy(hip):
+    """The asynchronous copy covers max(1024, 2 x last count + 256) records; a hop with more decodes than that is completed by the
+    synchronous remainder copy from the slot's own device list - also when the other slot has decoded in between."""
+    cfg = dict(center=1500.0, width=40.0, step=0.25, depth=8, nbadsync_threshold=6)
+    channels = 48
+    rng = np.random.default_rng(5)
+    quiet = np.stack([synth.synth_audio(5184, [], 1000.0, rng) for _ in range(channels)])
+    msg = synth.random_message(rng)
+    loud = np.stack([synth.synth_audio(5184, [synth.Ping(msg, 200, 5, 1500.0 + 2.0, 12.0, 0.3)], 1000.0, rng) for _ in range(channels)])
+    with hip.HipDecoder(channels=channels, max_results=1 << 18, **cfg) as d:
+        d.submit_audio(loud)
+        d.decode()
+        want_loud = d.results().copy()
+        d.submit_audio(quiet)
+        d.decode()
+        want_quiet = d.results().copy()
+    assert len(want_loud) > 1024 + 256 and len(want_quiet) < 256          # the estimate after a quiet hop is 1024: short for the loud one
+    with hip.HipDecoder(channels=channels, max_results=1 << 18, **cfg) as d:
+        d.input_slot(0)[:] = quiet
+        d.submit_slot(0)
+        d.decode()
+        d.fetch_async(0)
+        r, _ = d.fetch_wait(0)
+        assert r.tobytes() == want_quiet.tobytes()
+        d.input_slot(1)[:] = loud
+        d.submit_slot(1)
+        d.decode()
+        d.fetch_async(1)
+        d.input_slot(0)[:] = quiet                                          # slot 0 decodes while slot 1 still waits to be fetched
+        d.submit_slot(0)
+        d.decode()
+        d.fetch_async(0)
+        r1, _ = d.fetch_wait(1)
+        r0, _ = d.fetch_wait(0)
+        assert r1.tobytes() == want_loud.tobytes() and r0.tobytes() == want_quiet.tobytes()
+
+
+def test_slot_state_errors(hip):
+    with hip.HipDecoder(channels=2, **CFG) as d:
+        with pytest.raises(hip.Msk144Error) as e:
+            d.fetch_wait(0)                                                 # nothing in flight
+        assert e.value.code == -4
+        with pytest.raises(hip.Msk144Error):
+            d.input_slot(2)
+        d.input_slot(0)[:] = 0
+        d.submit_slot(0)
+        d.decode()
+        with pytest.raises(hip.Msk144Error) as e:
+            d.fetch_async(1)                                                # not the slot that was decoded
+        assert e.value.code == -4
+        d.fetch_async(0)
+        with pytest.raises(hip.Msk144Error) as e:
+            d.submit_slot(0)                                                # results not fetched yet
+        assert e.value.code == -4
+        d.fetch_wait(0)
+        d.submit_slot(0)
+        d.decode()
+        assert len(d.results()) == 0                                        # the plain calls read the list of the slot just decoded

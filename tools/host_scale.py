@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""The product PROGRAM at BASELINE scale: N real-time streams through `msk144hipdecoder --inputs-file=...` on one MI355X.
+
+Every stream is a FIFO fed at the real-time rate of the reference's input (12 ksps: the first 5184 samples, then 2592 samples
+every 216 ms, main.cu:269-294); the decoder runs the deep configuration (--search-width=500 --search-step=1 --scan-depth=6
+--nbadsync-threshold=3) and reports, per hop, where the host's wall time goes (--timing: ingest, window assembly, submit, wait
+for GPU + D2H, post-processing, print; device-side H2D / kernels / D2H from HIP events) and how many stream hops were answered
+later than the reference's 210 ms soft limit (main.cu:398-403).
+
+    python tools/host_scale.py --streams 1024 --hops 20            # paced, prints one JSON line
+    python tools/host_scale.py --streams 1024 --hops 20 --pace-ms 0  # as fast as the pipes deliver (throughput of the host loop)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+EXE = os.path.join(ROOT, "msk144cudecoder_amd", "msk144hipdecoder")
+DEEP = ["--search-width=500", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=3"]
+
+
+def make_streams(n_streams: int, n_hops: int, seed: int = 7):
+    """int16 [n_streams][5184 + n_hops*2592]: AWGN sigma = 1000 LSB; every 4th stream carries one 0 dB ping (bench.py's recipe)."""
+    from msk144cudecoder_amd import synth
+    n = 5184 + n_hops * 2592
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0.0, 1000.0, size=(n_streams, n)).astype(np.float32)
+    sent = {}
+    amp = np.sqrt(2.0 * 1000.0 ** 2 * (2500.0 / 6000.0))
+    for c in range(0, n_streams, 4):
+        msg = synth.random_message(rng)
+        frames = int(rng.integers(3, 7))
+        start = int(rng.integers(0, n - frames * 864))
+        freq = 1500.0 + float(rng.uniform(-240, 240))
+        bb = synth.modulate_frame(synth.frame_bits(synth.encode_message(msg)))
+        t = np.arange(start, start + frames * 864)
+        x[c, start:start + frames * 864] += (amp * np.real(np.tile(bb, frames) * np.exp(1j * (2 * np.pi * freq * t / 12000.0 + rng.uniform(0, 6.28))))).astype(np.float32)
+        sent[c] = "".join(str(int(b)) for b in msg)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16), sent
+
+
+def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = 100, timeout_s: float = 600.0):
+    streams, sent = make_streams(n_streams, n_hops)
+    tmp = tempfile.mkdtemp(prefix="msk144_fifos_")
+    paths = [os.path.join(tmp, f"s{c:05d}.fifo") for c in range(n_streams)]
+    for p in paths:
+        os.mkfifo(p)
+    lst = os.path.join(tmp, "inputs.txt")
+    with open(lst, "w") as f:
+        f.write("\n".join(paths) + "\n")
+    cmd = [EXE] + DEEP + ["--print-bits", "--timing", f"--hop-timeout-ms={hop_timeout_ms}", f"--inputs-file={lst}"] + list(extra_args)
+    out_path, err_path = os.path.join(tmp, "stdout.txt"), os.path.join(tmp, "stderr.txt")
+    with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
+        proc = subprocess.Popen(cmd, stdout=fo, stderr=fe)
+        fds = [None] * n_streams
+        errors = []
+
+        def open_range(lo, hi):
+            try:
+                for c in range(lo, hi):
+                    fds[c] = os.open(paths[c], os.O_WRONLY)          # returns once the decoder has opened its end
+            except OSError as e:
+                errors.append(e)
+
+        per = -(-n_streams // feeders)
+        ths = [threading.Thread(target=open_range, args=(k * per, min(n_streams, (k + 1) * per))) for k in range(feeders)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        if errors or any(fd is None for fd in fds):
+            proc.kill()
+            raise RuntimeError(f"could not open the FIFOs for writing: {errors[:1]}")
+        raw = streams.view(np.uint8).reshape(n_streams, -1)
+        t0 = time.monotonic()
+        start = threading.Barrier(feeders)
+
+        def feed(lo, hi):
+            try:
+                start.wait()
+                for h in range(-1, n_hops):
+                    if h >= 0 and pace_ms > 0:
+                        time.sleep(max(0.0, t0 + 0.5 + pace_ms * 1e-3 * (h + 1) - time.monotonic()))
+                    a, b = (0, 5184 * 2) if h < 0 else (5184 * 2 + h * 5184, 5184 * 2 + (h + 1) * 5184)
+                    for c in range(lo, hi):
+                        os.write(fds[c], raw[c, a:b].tobytes())
+            except OSError as e:
+                errors.append(e)
+            finally:
+                for c in range(lo, hi):
+                    os.close(fds[c])
+
+        ths = [threading.Thread(target=feed, args=(k * per, min(n_streams, (k + 1) * per))) for k in range(feeders)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=timeout_s)
+        rc = proc.wait(timeout=timeout_s)
+    wall = time.monotonic() - t0
+    out = open(out_path, errors="replace").read()
+    err = open(err_path, errors="replace").read()
+    for p in paths + [lst, out_path, err_path]:
+        os.unlink(p)
+    os.rmdir(tmp)
+    res = {"streams": n_streams, "hops_per_stream": n_hops + 1, "pace_ms": pace_ms, "returncode": rc, "feeder_errors": len(errors), "wall_s": round(wall, 3),
+           "options": " ".join(DEEP), "lines": out.count("\n") - 1}
+    m = re.search(r"(\d+) batches, (\d+) stream hops, (\d+) late, worst latency (\d+) ms", err)
+    if m:
+        res.update(batches=int(m.group(1)), stream_hops=int(m.group(2)), late_hops=int(m.group(3)), worst_latency_ms=int(m.group(4)))
+    rows = {}
+    for name, mean, worst in re.findall(r"timing: (.+?)\s+mean\s+([\d.]+) ms\s+max\s+([\d.]+) ms", err):
+        rows[name.strip()] = {"mean_ms": float(mean), "max_ms": float(worst)}
+    res["host_ms_per_batch"] = rows
+    m = re.search(r"device per batch \(HIP events\): (.*) ms", err)
+    if m:
+        res["device_ms_per_batch"] = {k.strip(): float(v) for k, v in re.findall(r"([A-Za-z0-9 ]+?)\s+([\d.]+)(?:\s{2}|$)", m.group(1))}
+    decoded = {}
+    for ch, bits in re.findall(r"ch=(\d+); .*?bits='([01]{77})'", out):
+        decoded.setdefault(int(ch), set()).add(bits)
+    res["streams_with_ping"] = len(sent)
+    res["pings_decoded"] = sum(1 for c, b in sent.items() if b in decoded.get(c, set()))
+    res["warnings"] = err.count("Warning: Working loop takes too much time")
+    res["stderr_tail"] = err[-600:] if rc != 0 else ""
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=1024)
+    ap.add_argument("--hops", type=int, default=20)
+    ap.add_argument("--pace-ms", type=float, default=216.0)
+    ap.add_argument("--hop-timeout-ms", type=int, default=100)
+    a = ap.parse_args()
+    print(json.dumps(run(a.streams, a.hops, a.pace_ms, hop_timeout_ms=a.hop_timeout_ms)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
