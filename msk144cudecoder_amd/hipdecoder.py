@@ -65,7 +65,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MSK144HIP_LIBRARY") or LIB_PATH      # MSK144HIP_LIBRARY: same-box A/B of two builds (tools/)
     # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7.  If torch were
     # imported AFTER this library, two runtimes would be live and the second finds no GPU.  Importing
     # torch first makes the dynamic linker bind libmsk144hip.so to the runtime torch already loaded.
