@@ -11,6 +11,7 @@
 #include <getopt.h>
 #include <poll.h>
 #include <sys/resource.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -54,6 +55,7 @@ void show_help(const char* prog)
     std::cout << "                   --inputs=F1,F2,...          Decode several raw streams (files or FIFOs) as one GPU batch per hop instead of stdin; lines then carry ch=<index>." << std::endl;
     std::cout << "                   --inputs-file=PATH          The same, one stream path per line (for hundreds of streams)." << std::endl;
     std::cout << "                   --hop-timeout-ms=N          With --inputs: how long a batch waits for lagging streams once the first one has a hop ready. Default=216 (one hop)." << std::endl;
+    std::cout << "                   --connect-timeout-ms=N      With --inputs: how long a FIFO may stay without a writer before it counts as ended. Default=10000." << std::endl;
     std::cout << "                   --skip-wav-header           Drop the first 44 bytes of every stream (the reference decodes a RIFF header as 22 samples). Default off." << std::endl;
     std::cout << "                   --reference-decode-cache    Reproduce the reference's per-window text cache, whose comparator is always false: every decode of a window prints the text of the first one. Default: each distinct payload gets its own text." << std::endl;
     std::cout << "                   --strict-decode             Accepted for compatibility (this is the default now)." << std::endl;
@@ -116,6 +118,8 @@ void print_lines(int nch, const std::vector<std::vector<FilteredResult>>& lines)
 struct Stream
 {
     int fd = -1;
+    bool fifo = false;            // a FIFO reads 0 bytes while no writer has connected yet: that is not its end
+    bool connected = false;       // first byte seen
     bool eof = false;
     bool first = true;            // next hop is the 5184-sample fill (main.cu:271-283), later ones 2592 (:284-294)
     size_t skip = 0;              // header bytes still to drop
@@ -164,6 +168,7 @@ int main(int argc, char* const argv[])
     bool center_set = false;
     bool skip_wav = false;
     int hop_timeout_ms = 216;
+    int connect_timeout_ms = 10000;
     bool timing = false;
     std::vector<std::string> input_paths;
 
@@ -184,6 +189,7 @@ int main(int argc, char* const argv[])
                                            {"hop-timeout-ms", required_argument, 0, 0},
                                            {"inputs-file", required_argument, 0, 0},
                                            {"timing", no_argument, 0, 0},
+                                           {"connect-timeout-ms", required_argument, 0, 0},
                                            {0, 0, 0, 0}};
     while(true)
     {
@@ -221,6 +227,7 @@ int main(int argc, char* const argv[])
             break;
         }
         case 16: timing = true; break;
+        case 17: connect_timeout_ms = atoi(optarg); break;
         default: show_help(argv[0]); return 0;
         }
     }
@@ -351,7 +358,10 @@ int main(int argc, char* const argv[])
         }
         st[c].skip = skip_wav ? 44 : 0;
         st[c].pending.reserve(win_bytes);
+        struct stat sb{};
+        st[c].fifo = fstat(st[c].fd, &sb) == 0 && S_ISFIFO(sb.st_mode);
     }
+    const auto opened_at = Clock::now();
     unsigned char* stage[WindowDecoder::kSlots];
     for(int k = 0; k < WindowDecoder::kSlots; k++)
     {
@@ -466,6 +476,7 @@ int main(int argc, char* const argv[])
                 const ssize_t got = read(s.fd, chunk.data(), room < chunk.size() ? room : chunk.size());
                 if(got > 0)
                 {
+                    s.connected = true;
                     if(s.skip) s.skip -= static_cast<size_t>(got);
                     else s.pending.insert(s.pending.end(), chunk.begin(), chunk.begin() + got);
                     if(!s.skip && s.pending.size() == need)
@@ -475,6 +486,8 @@ int main(int argc, char* const argv[])
                     }
                     continue;
                 }
+                if(got == 0 && s.fifo && !s.connected && ms_between(opened_at, Clock::now()) < connect_timeout_ms)
+                    break;  // no writer on this FIFO yet: read() reports 0 bytes, which only means "nobody there so far"
                 if(got == 0)
                 {
                     // writer closed: what is left is a short read, exactly the reference's end-of-stream message
@@ -506,10 +519,11 @@ int main(int argc, char* const argv[])
         }
         if(!go)
         {
+            // sleep until more data arrives; a FIFO nobody writes to yet polls as hung-up at once, so it is left out of the set
             int n = 0;
             for(int c = 0; c < nch; c++)
-                if(!st[c].eof && !st[c].ready) pfd[n++] = {st[c].fd, POLLIN, 0};
-            poll(pfd.data(), static_cast<nfds_t>(n), ready > 0 ? 5 : 50);
+                if(!st[c].eof && !st[c].ready && (st[c].connected || !st[c].fifo)) pfd[n++] = {st[c].fd, POLLIN, 0};
+            poll(pfd.data(), static_cast<nfds_t>(n), ready > 0 ? 5 : (n > 0 ? 50 : 10));
             continue;
         }
 

@@ -1,0 +1,160 @@
+// TEST-ONLY stand-in for libmsk144hip.so: the entry points msk144hipdecoder's host loop calls, with no GPU behind them, so that
+// the loop's own logic (non-blocking ingest, batch policy, two-slot pipeline, post-processing thread, deadline accounting, end of
+// stream) runs under `pytest -m "not gpu"`.  It decodes nothing: a "decode" takes MSK144_STUB_DECODE_MS milliseconds of wall time on
+// a worker thread (the asynchronous GPU) and yields one record per channel whose window's first sample is 0x7777.  Its payload is a
+// telemetry message (i3 = 0, n3 = 5: 71 bits printed as hex by the text layer) holding the channel and the second sample of each
+// window half - enough to check from stdout that every hop of every stream reached the decoder once, in order, in its own slot.
+#include "../../include/msk144hip.h"
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct msk144_handle
+{
+    msk144_params p;
+    std::vector<int16_t> in[MSK144_SLOTS];
+    std::vector<msk144_result> out[MSK144_SLOTS];
+    std::vector<float> seg[MSK144_SLOTS];
+    std::future<void> job[MSK144_SLOTS];
+    bool pending[MSK144_SLOTS] = {false, false};
+    std::future<void> last;  // decodes run one after the other, like kernels on one stream
+    int cur = 0;
+    int decode_ms = 5;
+    std::string error;
+};
+
+extern "C" {
+
+void msk144_default_params(msk144_params* p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->center_hz = 1500.0f;
+    p->width_hz = 200.0f;
+    p->step_hz = 2.0f;
+    p->scan_depth = 4;
+    p->nbadsync_threshold = 1;
+    p->read_mode = 1;
+    p->analytic_method = 2;
+    p->channels = 1;
+}
+
+int msk144_create(const msk144_params* p, msk144_handle** out)
+{
+    auto* h = new msk144_handle();
+    h->p = *p;
+    if(const char* e = std::getenv("MSK144_STUB_DECODE_MS")) h->decode_ms = std::atoi(e);
+    *out = h;
+    return MSK144_OK;
+}
+
+void msk144_destroy(msk144_handle* h)
+{
+    if(!h) return;
+    for(auto& j : h->job)
+        if(j.valid()) j.wait();
+    delete h;
+}
+
+const char* msk144_last_error(const msk144_handle* h) { return h ? h->error.c_str() : "stub"; }
+
+int msk144_geometry(const msk144_handle* h, int32_t* f, int32_t* d, int32_t* k)
+{
+    const int F = 2 * static_cast<int>((h->p.width_hz / 2) / h->p.step_hz) + 1;
+    if(f) *f = F;
+    if(d) *d = h->p.scan_depth;
+    if(k) *k = F * h->p.scan_depth * 8;
+    return MSK144_OK;
+}
+
+int msk144_frequency(const msk144_handle* h, int32_t b, float* hz)
+{
+    *hz = h->p.center_hz - static_cast<int>((h->p.width_hz / 2) / h->p.step_hz) * h->p.step_hz + b * h->p.step_hz;
+    return MSK144_OK;
+}
+
+int msk144_set_profiling(msk144_handle*, int32_t) { return MSK144_OK; }
+
+int msk144_stage_times(msk144_handle*, float* ms, int32_t*, int32_t)
+{
+    for(int i = 0; i < MSK144_T_COUNT; i++) ms[i] = 0.0f;
+    return MSK144_OK;
+}
+
+int msk144_input_slot(msk144_handle* h, int32_t s, void** w, size_t* bytes)
+{
+    if(s < 0 || s >= MSK144_SLOTS) return MSK144_EINVAL;
+    const size_t n = static_cast<size_t>(h->p.channels) * MSK144_WINDOW_SAMPLES;
+    if(h->in[s].size() != n) h->in[s].assign(n, 0);
+    *w = h->in[s].data();
+    if(bytes) *bytes = n * sizeof(int16_t);
+    return MSK144_OK;
+}
+
+int msk144_submit_slot(msk144_handle* h, int32_t s)
+{
+    if(h->pending[s])
+    {
+        h->error = "stub: slot submitted again before its results were fetched";
+        return MSK144_ESTATE;
+    }
+    h->cur = s;
+    return MSK144_OK;
+}
+
+int msk144_decode(msk144_handle*) { return MSK144_OK; }
+
+int msk144_fetch_async(msk144_handle* h, int32_t s)
+{
+    if(s != h->cur || h->pending[s])
+    {
+        h->error = "stub: fetch of the wrong slot";
+        return MSK144_ESTATE;
+    }
+    h->pending[s] = true;
+    std::shared_future<void> before = h->last.valid() ? h->last.share() : std::shared_future<void>();
+    std::promise<void> done;
+    h->last = done.get_future();
+    h->job[s] = std::async(std::launch::async, [h, s, before, done = std::move(done)]() mutable {
+        if(before.valid()) before.wait();
+        std::this_thread::sleep_for(std::chrono::milliseconds(h->decode_ms));
+        h->out[s].clear();
+        h->seg[s].assign(static_cast<size_t>(h->p.channels) * 8, 1.0f);
+        for(int c = 0; c < h->p.channels; c++)
+        {
+            const int16_t* w = h->in[s].data() + static_cast<size_t>(c) * MSK144_WINDOW_SAMPLES;
+            if(w[0] != 0x7777) continue;
+            msk144_result r{};
+            r.channel = c;
+            r.item = c;
+            r.f0 = 1500.0f;
+            const uint64_t v = (static_cast<uint64_t>(c) << 32) | (static_cast<uint64_t>(static_cast<uint16_t>(w[1])) << 16) |
+                               static_cast<uint16_t>(w[MSK144_HOP_SAMPLES + 1]);
+            uint8_t bits[80] = {0};
+            for(int i = 0; i < 64; i++) bits[7 + i] = (v >> (63 - i)) & 1u;  // 71-bit field, MSB first: 7 leading zeros + 64 bits
+            bits[71] = 1;                                                     // n3 = 5 (101), i3 = 0 (000)
+            bits[73] = 1;
+            for(int i = 0; i < 80; i++) r.message[i / 8] |= static_cast<uint8_t>(bits[i] << (7 - (i % 8)));
+            h->out[s].push_back(r);
+        }
+        done.set_value();
+    });
+    return MSK144_OK;
+}
+
+int msk144_fetch_wait(msk144_handle* h, int32_t s, const msk144_result** rec, int32_t* n, const float** seg)
+{
+    if(!h->pending[s]) return MSK144_ESTATE;
+    h->job[s].wait();
+    h->pending[s] = false;
+    *rec = h->out[s].data();
+    *n = static_cast<int32_t>(h->out[s].size());
+    if(seg) *seg = h->seg[s].data();
+    return MSK144_OK;
+}
+
+}  // extern "C"

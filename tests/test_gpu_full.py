@@ -84,11 +84,17 @@ def test_1024_channel_batch_properties(orc, hip, parity_report):
             d1.decode()
             assert d1.dump_candidates(0).tobytes() == blob              # batch == single, bit for bit
     # production list against the oracle DIRECTLY: 16 sampled channels spread over the 64-channel blocks, eight with a decoded
-    # ping and eight noise-only - the set of (item, payload) must be the oracle's decode_window set
+    # ping and eight noise-only - the records are the accepted candidates of the channel's dump, and the dump agrees with the oracle
     with_ping = sorted(decoded_channels & pinged)
     noise = [c for c in range(1024) if c not in pinged]
     sample = [with_ping[i * len(with_ping) // 8] for i in range(8)] + [noise[i * len(noise) // 8] for i in range(8)]
-    report = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_audio(wins[2, ch], 2) for ch in sample})
+    dumps = {}
+    with hip.HipDecoder(channels=1, **DEEP) as d1:
+        for ch in sample:
+            d1.submit_audio(wins[2, ch])
+            d1.decode()
+            dumps[ch] = d1.dump_candidates(0)                           # single == batch bit for bit (asserted above)
+    report = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_audio(wins[2, ch], 2) for ch in sample}, dumps)
     assert report["channels"] == 16 and report["decodes"] >= 8, report
     parity_report("production_path_1024ch_vs_oracle", report)
 
@@ -177,7 +183,13 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
     no_ping = [c for c in range(nch) if c not in truth]
     gl = sorted(good)
     sample = [gl[i * len(gl) // 8] for i in range(8)] + [no_ping[i * len(no_ping) // 8] for i in range(8)]
-    direct = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_iq(wins[ch]) for ch in sample})
+    dumps = {}
+    with hip.HipDecoder(read_mode=2, channels=1, **cfg) as d1:
+        for ch in sample:
+            d1.submit_iq(wins[ch])
+            d1.decode()
+            dumps[ch] = d1.dump_candidates(0)
+    direct = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_iq(wins[ch]) for ch in sample}, dumps)
     assert direct["channels"] == 16 and direct["decodes"] >= 8, direct
     parity_report("production_path_config4_vs_oracle", direct)
     parity_report("config4_iq_4096", dict(channels=nch, decodes=int(len(res1)), pinged=len(truth), pinged_decoded=len(good),

@@ -26,7 +26,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-EXE = os.path.join(ROOT, "msk144cudecoder_amd", "msk144hipdecoder")
+EXE = os.environ.get("MSK144_DECODER_EXE") or os.path.join(ROOT, "msk144cudecoder_amd", "msk144hipdecoder")   # the override: CPU tests of the loop against tests/stub_hip
 DEEP = ["--search-width=500", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=3"]
 
 
@@ -50,7 +50,7 @@ def make_streams(n_streams: int, n_hops: int, seed: int = 7):
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16), sent
 
 
-def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = 100, timeout_s: float = 600.0):
+def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = 100, timeout_s: float = 180.0):
     streams, sent = make_streams(n_streams, n_hops)
     tmp = tempfile.mkdtemp(prefix="msk144_fifos_")
     paths = [os.path.join(tmp, f"s{c:05d}.fifo") for c in range(n_streams)]
@@ -104,9 +104,20 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
         ths = [threading.Thread(target=feed, args=(k * per, min(n_streams, (k + 1) * per))) for k in range(feeders)]
         for t in ths:
             t.start()
+        deadline = time.monotonic() + timeout_s + n_hops * pace_ms * 1e-3
         for t in ths:
-            t.join(timeout=timeout_s)
-        rc = proc.wait(timeout=timeout_s)
+            t.join(timeout=max(0.1, deadline - time.monotonic()))
+        if any(t.is_alive() for t in ths):
+            proc.kill()                                   # a decoder that stopped reading: unblock the feeders and report it
+            errors.append(TimeoutError("decoder stopped reading its inputs"))
+            for t in ths:
+                t.join(timeout=10)
+        try:
+            rc = proc.wait(timeout=max(1.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            rc = proc.wait()
+            errors.append(TimeoutError("decoder did not exit after its inputs ended"))
     wall = time.monotonic() - t0
     out = open(out_path, errors="replace").read()
     err = open(err_path, errors="replace").read()
@@ -131,7 +142,7 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
     res["streams_with_ping"] = len(sent)
     res["pings_decoded"] = sum(1 for c, b in sent.items() if b in decoded.get(c, set()))
     res["warnings"] = err.count("Warning: Working loop takes too much time")
-    res["stderr_tail"] = err[-600:] if rc != 0 else ""
+    res["stderr_tail"] = err[-600:] if (rc != 0 or errors) else ""
     return res
 
 
