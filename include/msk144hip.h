@@ -205,6 +205,10 @@ int msk144_segment_power(msk144_handle* h, float* out /*[channels][8]*/);
  * msk144_results. */
 int msk144_input_slot(msk144_handle* h, int32_t slot, void** host_windows, size_t* bytes);
 int msk144_submit_slot(msk144_handle* h, int32_t slot);
+/* The same for a hop that covers only the first n_channels windows of the slot (1..channels): every kernel, copy and result of
+ * the hop is sized for n_channels, so a partial batch - streams that lag sit it out - costs what its streams cost, not what the
+ * handle's capacity costs.  Record channel numbers are positions in the slot. */
+int msk144_submit_slot_n(msk144_handle* h, int32_t slot, int32_t n_channels);
 int msk144_fetch_async(msk144_handle* h, int32_t slot);
 int msk144_fetch_wait(msk144_handle* h, int32_t slot, const msk144_result** records, int32_t* n, const float** seg_power /*[channels][8]*/);
 

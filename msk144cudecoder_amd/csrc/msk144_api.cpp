@@ -39,6 +39,7 @@ struct msk144_handle
     std::vector<void*> allocs;
 
     int llr_block = 1;  // channels per softbits->index->LDPC block
+    int active = 1;     // channels the current hop covers (msk144_submit_slot_n: the first n of the slot); <= st.channels
     bool have_window = false;
     bool decoded = false;
     bool profiling = false;
@@ -116,10 +117,23 @@ int dev_alloc(msk144_handle* h, T** p, size_t count)
     return MSK144_OK;
 }
 
+size_t window_bytes(const msk144_handle* h)
+{
+    return (h->params.read_mode == 2) ? 2 * kWindowSamples : kWindowSamples * sizeof(int16_t);
+}
+
 size_t input_bytes(const msk144_handle* h)
 {
-    const size_t per = (h->params.read_mode == 2) ? 2 * kWindowSamples : kWindowSamples * sizeof(int16_t);
-    return per * h->params.channels;
+    return window_bytes(h) * h->params.channels;
+}
+
+// the store as the kernels of the current hop see it: the first `active` channels
+DeviceStore active_store(const msk144_handle* h)
+{
+    DeviceStore st = h->st;
+    st.channels = h->active;
+    st.nch = h->active;
+    return st;
 }
 
 hipEvent_t ev_take(msk144_handle* h)
@@ -219,7 +233,7 @@ int ensure_slots(msk144_handle* h)
 int copy_windows_in(msk144_handle* h, const void* host_windows)
 {
     ev_begin(h, MSK144_T_H2D);
-    hipError_t e = hipMemcpyAsync(h->d_input, host_windows, input_bytes(h), hipMemcpyHostToDevice, h->stream);
+    hipError_t e = hipMemcpyAsync(h->d_input, host_windows, window_bytes(h) * h->active, hipMemcpyHostToDevice, h->stream);
     ev_end(h, MSK144_T_H2D);
     if(e != hipSuccess) return fail(h, MSK144_EHIP, std::string("hipMemcpyAsync(windows): ") + hipGetErrorString(e));
     return MSK144_OK;
@@ -228,8 +242,9 @@ int copy_windows_in(msk144_handle* h, const void* host_windows)
 int run_frontend(msk144_handle* h, const void* d_in)
 {
     ev_begin(h, MSK144_T_FRONTEND);
-    if(h->params.read_mode == 2) launch_frontend_iq(h->st, static_cast<const int8_t*>(d_in), h->stream);
-    else launch_frontend_audio(h->st, static_cast<const int16_t*>(d_in), h->params.analytic_method, h->d_twiddle, h->d_fft_mask, h->stream);
+    const DeviceStore st = active_store(h);
+    if(h->params.read_mode == 2) launch_frontend_iq(st, static_cast<const int8_t*>(d_in), h->stream);
+    else launch_frontend_audio(st, static_cast<const int16_t*>(d_in), h->params.analytic_method, h->d_twiddle, h->d_fft_mask, h->stream);
     ev_end(h, MSK144_T_FRONTEND);
     HIP_TRY(h, hipGetLastError());
     h->have_window = true;
@@ -318,6 +333,8 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     st.nbadsync_threshold = params->nbadsync_threshold;
     st.ch0 = 0;
     st.nch = st.channels;
+    st.gate_early = h->llr_block < st.channels ? 1 : 0;
+    h->active = st.channels;
     const long long total = static_cast<long long>(st.channels) * st.K;
     long long maxr = params->max_results > 0 ? params->max_results : (1 << 20);
     if(maxr > total) maxr = total;
@@ -468,6 +485,7 @@ int msk144_submit_audio(msk144_handle* h, const int16_t* windows)
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
     h->cur_slot = 0;
+    h->active = h->st.channels;
     int rc = copy_windows_in(h, windows);
     return rc == MSK144_OK ? run_frontend(h, h->d_input) : rc;
 }
@@ -479,6 +497,7 @@ int msk144_submit_iq(msk144_handle* h, const int8_t* windows)
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
     h->cur_slot = 0;
+    h->active = h->st.channels;
     int rc = copy_windows_in(h, windows);
     return rc == MSK144_OK ? run_frontend(h, h->d_input) : rc;
 }
@@ -490,6 +509,7 @@ int msk144_submit_audio_device(msk144_handle* h, const int16_t* d_windows)
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
     h->cur_slot = 0;
+    h->active = h->st.channels;
     return run_frontend(h, d_windows);
 }
 
@@ -500,6 +520,7 @@ int msk144_submit_iq_device(msk144_handle* h, const int8_t* d_windows)
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
     h->cur_slot = 0;
+    h->active = h->st.channels;
     return run_frontend(h, d_windows);
 }
 
@@ -509,6 +530,8 @@ int msk144_submit_analytic(msk144_handle* h, const float* windows)
     HIP_TRY(h, hipSetDevice(h->params.device));
     HIP_TRY(h, hipMemcpyAsync(h->st.analytic, windows, sizeof(float2) * kWindowSamples * h->st.channels, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->cur_slot = 0;
+    h->active = h->st.channels;
     h->have_window = true;
     h->decoded = false;
     return MSK144_OK;
@@ -524,20 +547,21 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
         return fail(h, MSK144_ENOTRETAINED, "blocked staging runs softbits, index and LDPC together per channel block; a partial stage run needs llr_block_channels = channels");
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
+    const DeviceStore cur = active_store(h);
     if(stages & MSK144_STAGE_SCAN)
     {
         ev_begin(h, MSK144_T_SCAN);
-        launch_scan(h->st, h->tpl, h->stream);
+        launch_scan(cur, h->tpl, h->stream);
         ev_end(h, MSK144_T_SCAN);
     }
     // softbits -> index -> LDPC, one channel block at a time (one block = everything unless llr_block_channels says otherwise)
     if(stages & mid)
     {
-        DeviceStore blk = h->st;
-        for(int ch0 = 0; ch0 < h->st.channels; ch0 += h->llr_block)
+        DeviceStore blk = cur;
+        for(int ch0 = 0; ch0 < cur.channels; ch0 += h->llr_block)
         {
             blk.ch0 = ch0;
-            blk.nch = h->st.channels - ch0 < h->llr_block ? h->st.channels - ch0 : h->llr_block;
+            blk.nch = cur.channels - ch0 < h->llr_block ? cur.channels - ch0 : h->llr_block;
             if(stages & MSK144_STAGE_SOFTBITS)
             {
                 ev_begin(h, MSK144_T_SOFTBITS);
@@ -560,7 +584,7 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
     }
     if(stages & MSK144_STAGE_COLLECT)
     {
-        DeviceStore out = h->st;
+        DeviceStore out = cur;
         if(h->slots_ready) out.results = h->slots[h->cur_slot].d_records;  // the record list of the slot being decoded
         ev_begin(h, MSK144_T_COLLECT);
         launch_collect(out, h->stream);
@@ -647,13 +671,20 @@ int msk144_input_slot(msk144_handle* h, int32_t slot, void** host_windows, size_
 
 int msk144_submit_slot(msk144_handle* h, int32_t slot)
 {
+    return msk144_submit_slot_n(h, slot, h ? h->st.channels : 0);
+}
+
+int msk144_submit_slot_n(msk144_handle* h, int32_t slot, int32_t n_channels)
+{
     if(!h || slot < 0 || slot >= MSK144_SLOTS) return fail(h, MSK144_EINVAL, "bad argument");
+    if(n_channels < 1 || n_channels > h->st.channels) return fail(h, MSK144_EINVAL, "n_channels must be 1..channels");
     int rc = ensure_slots(h);
     if(rc != MSK144_OK) return rc;
     if(h->slots[slot].pending) return fail(h, MSK144_ESTATE, "slot submitted again before its results were fetched (msk144_fetch_wait)");
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
     h->cur_slot = slot;
+    h->active = n_channels;
     rc = copy_windows_in(h, h->slots[slot].in);
     return rc == MSK144_OK ? run_frontend(h, h->d_input) : rc;
 }
@@ -674,7 +705,7 @@ int msk144_fetch_async(msk144_handle* h, int32_t slot)
     sl.copied = static_cast<int32_t>(guess);
     ev_begin(h, MSK144_T_D2H);
     hipError_t e = hipMemcpyAsync(sl.out_count, h->st.result_count, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
-    if(e == hipSuccess) e = hipMemcpyAsync(sl.out_seg, h->st.seg_power, sizeof(float) * 8 * h->st.channels, hipMemcpyDeviceToHost, h->stream);
+    if(e == hipSuccess) e = hipMemcpyAsync(sl.out_seg, h->st.seg_power, sizeof(float) * 8 * h->active, hipMemcpyDeviceToHost, h->stream);
     if(e == hipSuccess) e = hipMemcpyAsync(sl.out, sl.d_records, sizeof(msk144_result) * static_cast<size_t>(sl.copied), hipMemcpyDeviceToHost, h->stream);
     ev_end(h, MSK144_T_D2H);
     if(e == hipSuccess) e = hipEventRecord(sl.done, h->stream);

@@ -36,6 +36,9 @@ struct DeviceStore
     // channel.  scan, front ends and collect always cover all `channels`.
     int32_t ch0;
     int32_t nch;
+    // LLR rows do not outlive their block (the handle's block is smaller than its channel capacity): a candidate the nbadsync
+    // gate is going to drop is not demodulated beyond its sync check (softbits_kernel<true>)
+    int32_t gate_early;
 
     const float* freq;        // [F] Hz, host-computed as msk_context.cuh:135
     const float2* cb42;       // [42] sync template (re, im), for kernels that index it per lane

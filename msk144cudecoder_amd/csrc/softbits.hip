@@ -405,8 +405,8 @@ void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t
     a.total_tiles = st.nch * st.F;
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
     const int grid = a.tiles_per_xcd * 8;
-    // LLR rows are retained only when one block covers every channel (msk144_api.cpp: dumps, parity tests)
-    if(st.nch < st.channels) hipLaunchKernelGGL(softbits_kernel<true>, dim3(grid), dim3(kSbThreads), 0, stream, a);
+    // LLR rows are retained only when one block covers every channel of the handle (msk144_api.cpp: dumps, parity tests)
+    if(st.gate_early) hipLaunchKernelGGL(softbits_kernel<true>, dim3(grid), dim3(kSbThreads), 0, stream, a);
     else hipLaunchKernelGGL(softbits_kernel<false>, dim3(grid), dim3(kSbThreads), 0, stream, a);
 }
 

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "msk144_submit_analytic", "msk144_decode", "msk144_decode_stages", "msk144_synchronize", "msk144_results",
     "msk144_result_count", "msk144_results_device", "msk144_set_channel_base", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
-    "msk144_input_slot", "msk144_submit_slot", "msk144_fetch_async", "msk144_fetch_wait",
+    "msk144_input_slot", "msk144_submit_slot", "msk144_submit_slot_n", "msk144_fetch_async", "msk144_fetch_wait",
 )
 
 
@@ -103,6 +103,7 @@ def load_library(path: Optional[str] = None):
     L.msk144_stage_times.argtypes = [vp, vp, vp, i32]
     L.msk144_input_slot.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.msk144_submit_slot.argtypes = [vp, i32]
+    L.msk144_submit_slot_n.argtypes = [vp, i32, i32]
     L.msk144_fetch_async.argtypes = [vp, i32]
     L.msk144_fetch_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp)]
     if path is None:
@@ -229,8 +230,9 @@ class HipDecoder:
         a = np.frombuffer(raw, dtype=np.int8 if self.read_mode == 2 else np.int16)
         return a.reshape(self.channels, -1)
 
-    def submit_slot(self, slot: int):
-        self._chk(self.L.msk144_submit_slot(self.h, slot))
+    def submit_slot(self, slot: int, n_channels: int = 0):
+        """n_channels > 0: the hop covers only the first n_channels windows of the slot."""
+        self._chk(self.L.msk144_submit_slot_n(self.h, slot, n_channels) if n_channels else self.L.msk144_submit_slot(self.h, slot))
 
     def fetch_async(self, slot: int):
         self._chk(self.L.msk144_fetch_async(self.h, slot))

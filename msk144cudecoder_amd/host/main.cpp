@@ -126,7 +126,7 @@ struct Stream
     std::vector<unsigned char> pending;
     bool ready = false;           // a complete hop sits in `pending`
     Clock::time_point ready_at;
-    int last_slot = -1;           // staging slot that holds this stream's latest window
+    std::vector<unsigned char> window;  // the stream's current 5184-sample window (main.cu:269-294: fill, then shift by half)
     // deadline accounting (owned by the post-processing thread)
     long hops = 0, late = 0;
     long long worst_ms = 0;
@@ -136,8 +136,8 @@ struct Stream
 struct Batch
 {
     int slot = 0;
-    std::vector<bool> active;
-    std::vector<Clock::time_point> ready_at;  // per stream, meaningful where active
+    std::vector<int> streams;                  // the streams that have a hop in this batch, ascending
+    std::vector<Clock::time_point> ready_at;  // when each of them had its hop complete
     Clock::time_point go;                      // batch released by the policy
     double assemble_ms = 0.0, submit_ms = 0.0;
 };
@@ -358,6 +358,7 @@ int main(int argc, char* const argv[])
         }
         st[c].skip = skip_wav ? 44 : 0;
         st[c].pending.reserve(win_bytes);
+        st[c].window.assign(win_bytes, 0);
         struct stat sb{};
         st[c].fifo = fstat(st[c].fd, &sb) == 0 && S_ISFIFO(sb.st_mode);
     }
@@ -371,7 +372,6 @@ int main(int argc, char* const argv[])
             std::cerr << "msk144hip: " << dec.error() << std::endl;
             return 2;
         }
-        memset(stage[k], 0, win_bytes * nch);
     }
 
     // hand-over between this (ingest + submit) thread and the post-processing thread
@@ -411,11 +411,10 @@ int main(int argc, char* const argv[])
             warn_if_late(std::chrono::duration_cast<std::chrono::milliseconds>(p1 - b.go).count());
             // per-stream deadline: from "hop complete" to "lines printed" a stream has one hop period (216 ms) before its next
             // hop is due; the reference's soft limit of 210 ms (main.cu:398-403) is applied per stream
-            for(int c = 0; c < nch; c++)
+            for(size_t j = 0; j < b.streams.size(); j++)
             {
-                if(!b.active[c]) continue;
-                Stream& s = st[c];
-                const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(p1 - b.ready_at[c]).count();
+                Stream& s = st[b.streams[j]];
+                const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(p1 - b.ready_at[j]).count();
                 s.hops++;
                 if(ms > 210) s.late++;
                 if(ms > s.worst_ms) s.worst_ms = ms;
@@ -537,32 +536,28 @@ int main(int argc, char* const argv[])
             b.slot = free_slots.front();
             free_slots.pop_front();
         }
-        // 4. advance the window of the streams that have a hop, straight into the pinned slot: first half = second half of the
-        // stream's latest window (in this slot or the other one), second half = the new hop; the others sit this batch out
+        // 4. advance the window of every stream that has a hop (main.cu:284-288) and pack those windows back to back into the
+        // pinned slot; streams without a hop sit this batch out and cost nothing on the GPU
         const auto a0 = Clock::now();
-        b.active.assign(nch, false);
-        b.ready_at.assign(nch, a0);
         for(int c = 0; c < nch; c++)
         {
             Stream& s = st[c];
             if(!s.ready) continue;
-            b.active[c] = true;
-            b.ready_at[c] = s.ready_at;
-            unsigned char* w = stage[b.slot] + win_bytes * c;
-            if(s.first) memcpy(w, s.pending.data(), win_bytes);
+            if(s.first) memcpy(s.window.data(), s.pending.data(), win_bytes);
             else
             {
-                if(s.last_slot == b.slot) memmove(w, w + half, half);
-                else memcpy(w, stage[s.last_slot] + win_bytes * c + half, half);
-                memcpy(w + half, s.pending.data(), half);
+                memcpy(s.window.data(), s.window.data() + half, half);
+                memcpy(s.window.data() + half, s.pending.data(), half);
             }
+            memcpy(stage[b.slot] + win_bytes * b.streams.size(), s.window.data(), win_bytes);
+            b.streams.push_back(c);
+            b.ready_at.push_back(s.ready_at);
             s.first = false;
-            s.last_slot = b.slot;
             s.pending.clear();
             s.ready = false;
         }
         const auto a1 = Clock::now();
-        if(!dec.submit(b.slot, b.active))
+        if(!dec.submit(b.slot, b.streams))
         {
             std::cerr << "msk144hip: " << dec.error() << std::endl;
             return finish(2);

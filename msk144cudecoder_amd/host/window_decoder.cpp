@@ -36,7 +36,7 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
     snr_.resize(opt_.channels);
     filter_.resize(opt_.channels);
     calls_.resize(opt_.channels);
-    window_bytes_ = static_cast<size_t>(opt_.channels) * MSK144_WINDOW_SAMPLES * (opt_.read_mode == 2 ? 2 * sizeof(int8_t) : sizeof(int16_t));
+    window_bytes_ = MSK144_WINDOW_SAMPLES * (opt_.read_mode == 2 ? 2 * sizeof(int8_t) : sizeof(int16_t));
     if(opt_.profile) msk144_set_profiling(handle_, 1);
 }
 
@@ -69,10 +69,21 @@ bool WindowDecoder::process(const void* window, std::vector<FilteredResult>& lin
 
 bool WindowDecoder::process(const void* windows, const std::vector<bool>& active, std::vector<std::vector<FilteredResult>>& lines)
 {
-    void* in = stage(0);
+    unsigned char* in = static_cast<unsigned char*>(stage(0));
     if(!in) return false;
-    if(windows != in) std::memcpy(in, windows, window_bytes_);
-    return submit(0, active) && collect(0, lines);
+    std::vector<int> streams;
+    for(int c = 0; c < opt_.channels; c++)
+    {
+        if(c < static_cast<int>(active.size()) && !active[c]) continue;
+        std::memcpy(in + window_bytes_ * streams.size(), static_cast<const unsigned char*>(windows) + window_bytes_ * c, window_bytes_);
+        streams.push_back(c);
+    }
+    if(streams.empty())
+    {
+        lines.assign(opt_.channels, {});
+        return true;
+    }
+    return submit(0, streams) && collect(0, lines);
 }
 
 void* WindowDecoder::stage(int slot)
@@ -86,10 +97,10 @@ void* WindowDecoder::stage(int slot)
     return p;
 }
 
-bool WindowDecoder::submit(int slot, const std::vector<bool>& active)
+bool WindowDecoder::submit(int slot, const std::vector<int>& streams)
 {
-    active_[slot] = active;
-    int rc = msk144_submit_slot(handle_, slot);
+    streams_[slot] = streams;
+    int rc = msk144_submit_slot_n(handle_, slot, static_cast<int32_t>(streams.size()));
     if(rc == MSK144_OK) rc = msk144_decode(handle_);
     if(rc == MSK144_OK) rc = msk144_fetch_async(handle_, slot);
     if(rc != MSK144_OK)
@@ -121,15 +132,16 @@ bool WindowDecoder::collect(int slot, std::vector<std::vector<FilteredResult>>& 
         return false;
     }
     const auto t1 = Clock::now();
-    const std::vector<bool>& active = active_[slot];
+    const std::vector<int>& streams = streams_[slot];
     const size_t n_results = static_cast<size_t>(n);
 
-    // results arrive ordered by (channel, item): walk them channel by channel
+    // results arrive ordered by (position in the slot, item): walk them position by position
     size_t r = 0;
-    for(int c = 0; c < nch; c++)
+    for(size_t j = 0; j < streams.size(); j++)
     {
+        const int c = streams[j];
         std::vector<AcceptedCandidate> accepted;
-        for(; r < n_results && results[r].channel == c; r++)
+        for(; r < n_results && results[r].channel == static_cast<int32_t>(j); r++)
         {
             const msk144_result& res = results[r];
             AcceptedCandidate a;
@@ -140,8 +152,7 @@ bool WindowDecoder::collect(int slot, std::vector<std::vector<FilteredResult>>& 
             unpack_bits(res.message, a.bits);
             accepted.push_back(a);
         }
-        if(c < static_cast<int>(active.size()) && !active[c]) continue;  // ended stream: leave its state alone
-        snr_[c].update(&seg[static_cast<size_t>(c) * 8]);  // main.cu:388
+        snr_[c].update(&seg[j * 8]);  // main.cu:388
         lines[c] = postprocess_window(accepted, snr_[c].snr_int(), opt_.reference_cache_quirk, calls_[c], filter_[c]);
         if(opt_.print_bits)
         {

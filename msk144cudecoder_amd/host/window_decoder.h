@@ -79,9 +79,8 @@ public:
     int channels() const { return opt_.channels; }
 
     // One 5184-sample window per channel, [channels][5184] int16 or [channels][2*5184] int8 I/Q, decoded as one
-    // batch; lines[c] = output lines of channel c.  `active[c] == false` marks a stream that has ended: its
-    // slot is still decoded (the batch shape is fixed) but its results and state are left untouched.
-    // Returns false on a library error.
+    // batch; lines[c] = output lines of channel c.  `active[c] == false` marks a stream without a hop this time: it is
+    // left out of the batch and its state stays untouched.  Returns false on a library error.
     bool process(const void* windows, const std::vector<bool>& active, std::vector<std::vector<FilteredResult>>& lines);
     // single-stream convenience (channels == 1)
     bool process(const void* window, std::vector<FilteredResult>& lines);
@@ -90,9 +89,12 @@ public:
     // (asynchronous: H2D, front end, decode, D2H of count + records + segment powers), and collect it later - possibly on a
     // second thread while the other slot is being filled and submitted.  The reference's loop is strictly serial per hop
     // (main.cu:261-422).
+    // A hop covers the streams listed in `streams` (ascending): their windows sit back to back at positions 0, 1, ... of the slot,
+    // and the GPU work, the copies and the results of the hop are sized for that many windows - a stream that has no hop this
+    // time costs nothing.  lines[c] is indexed by STREAM.
     static constexpr int kSlots = MSK144_SLOTS;
     void* stage(int slot);
-    bool submit(int slot, const std::vector<bool>& active);
+    bool submit(int slot, const std::vector<int>& streams);
     bool collect(int slot, std::vector<std::vector<FilteredResult>>& lines, HopTiming* timing = nullptr);
     // average device milliseconds per hop of every stage (frontend, scan, softbits, index, ldpc, collect, h2d, d2h); needs
     // DecoderOptions::profile; waits for the GPU
@@ -107,8 +109,8 @@ private:
     std::vector<SnrTracker> snr_;
     std::vector<ResultFilter> filter_;
     std::vector<CallHashTable> calls_;
-    std::vector<bool> active_[kSlots];
-    size_t window_bytes_ = 0;  // per batch
+    std::vector<int> streams_[kSlots];  // streams of the hop in flight on each slot, by position
+    size_t window_bytes_ = 0;           // of one stream
 };
 
 }  // namespace msk144host

@@ -24,6 +24,7 @@ struct msk144_handle
     bool pending[MSK144_SLOTS] = {false, false};
     std::future<void> last;  // decodes run one after the other, like kernels on one stream
     int cur = 0;
+    int active[MSK144_SLOTS] = {0, 0};  // windows the hop in each slot covers
     int decode_ms = 5;
     std::string error;
 };
@@ -95,16 +96,20 @@ int msk144_input_slot(msk144_handle* h, int32_t s, void** w, size_t* bytes)
     return MSK144_OK;
 }
 
-int msk144_submit_slot(msk144_handle* h, int32_t s)
+int msk144_submit_slot_n(msk144_handle* h, int32_t s, int32_t n)
 {
+    if(n < 1 || n > h->p.channels) return MSK144_EINVAL;
     if(h->pending[s])
     {
         h->error = "stub: slot submitted again before its results were fetched";
         return MSK144_ESTATE;
     }
     h->cur = s;
+    h->active[s] = n;
     return MSK144_OK;
 }
+
+int msk144_submit_slot(msk144_handle* h, int32_t s) { return msk144_submit_slot_n(h, s, h->p.channels); }
 
 int msk144_decode(msk144_handle*) { return MSK144_OK; }
 
@@ -124,7 +129,7 @@ int msk144_fetch_async(msk144_handle* h, int32_t s)
         std::this_thread::sleep_for(std::chrono::milliseconds(h->decode_ms));
         h->out[s].clear();
         h->seg[s].assign(static_cast<size_t>(h->p.channels) * 8, 1.0f);
-        for(int c = 0; c < h->p.channels; c++)
+        for(int c = 0; c < h->active[s]; c++)
         {
             const int16_t* w = h->in[s].data() + static_cast<size_t>(c) * MSK144_WINDOW_SAMPLES;
             if(w[0] != 0x7777) continue;

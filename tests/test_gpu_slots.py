@@ -158,3 +158,33 @@ def test_slot_state_errors(hip):
         d.submit_slot(0)
         d.decode()
         assert len(d.results()) == 0                                        # the plain calls read the list of the slot just decoded
+
+
+def test_partial_hop_covers_only_its_streams(hip):
+    """msk144_submit_slot_n: a hop over the first n windows of the slot gives exactly the records of an n-channel handle (every
+    kernel, copy and result sized for n), whatever the handle's capacity and whatever a previous, larger hop left behind."""
+    capacity = 100                                   # > 64: blocked staging with gated softbits, two blocks for n = 70
+    wins = _windows(1, capacity, 21)[0]
+    with hip.HipDecoder(channels=capacity, max_results=1 << 16, **CFG) as d:
+        d.input_slot(0)[:] = wins
+        d.submit_slot(0)
+        d.decode()
+        d.fetch_async(0)
+        full, seg_full = d.fetch_wait(0)
+        for n, slot in ((5, 1), (70, 0), (1, 1)):
+            d.input_slot(slot)[:n] = wins[:n]
+            d.submit_slot(slot, n)
+            d.decode()
+            d.fetch_async(slot)
+            got, seg = d.fetch_wait(slot)
+            with hip.HipDecoder(channels=n, max_results=1 << 16, **CFG) as small:
+                small.submit_audio(wins[:n])
+                small.decode()
+                want = small.results().copy()
+                want_seg = small.segment_power().copy()
+            assert got.tobytes() == want.tobytes(), n
+            assert got.tobytes() == full[full["channel"] < n].tobytes(), n
+            assert np.array_equal(seg[:n].view(np.uint32), want_seg.view(np.uint32))
+        with pytest.raises(hip.Msk144Error):
+            d.submit_slot(0, capacity + 1)
+    assert len(full) > 50
