@@ -51,6 +51,10 @@ def make_streams(n_streams: int, n_hops: int, seed: int = 7):
 
 
 def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = 100, timeout_s: float = 180.0):
+    import resource
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    if soft < n_streams + 256:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (min(hard, n_streams + 256) if hard != resource.RLIM_INFINITY else n_streams + 256, hard))
     streams, sent = make_streams(n_streams, n_hops)
     tmp = tempfile.mkdtemp(prefix="msk144_fifos_")
     paths = [os.path.join(tmp, f"s{c:05d}.fifo") for c in range(n_streams)]
