@@ -54,7 +54,7 @@ void show_help(const char* prog)
     std::cout << " Additions of msk144hipdecoder (defaults in effect, as in the reference's code: search-width 200, scan-depth 4, nbadsync-threshold 1):" << std::endl;
     std::cout << "                   --inputs=F1,F2,...          Decode several raw streams (files or FIFOs) as one GPU batch per hop instead of stdin; lines then carry ch=<index>." << std::endl;
     std::cout << "                   --inputs-file=PATH          The same, one stream path per line (for hundreds of streams)." << std::endl;
-    std::cout << "                   --hop-timeout-ms=N          With --inputs: how long a batch waits for lagging streams once the first one has a hop ready. Default=216 (one hop)." << std::endl;
+    std::cout << "                   --hop-timeout-ms=N          With --inputs: how long a batch waits for further streams once the first one has a hop ready (a batch costs what its streams cost, so small batches are cheap and keep the latency of each stream low). Default=20." << std::endl;
     std::cout << "                   --connect-timeout-ms=N      With --inputs: how long a FIFO may stay without a writer before it counts as ended. Default=10000." << std::endl;
     std::cout << "                   --skip-wav-header           Drop the first 44 bytes of every stream (the reference decodes a RIFF header as 22 samples). Default off." << std::endl;
     std::cout << "                   --reference-decode-cache    Reproduce the reference's per-window text cache, whose comparator is always false: every decode of a window prints the text of the first one. Default: each distinct payload gets its own text." << std::endl;
@@ -167,7 +167,7 @@ int main(int argc, char* const argv[])
     DecoderOptions opt;
     bool center_set = false;
     bool skip_wav = false;
-    int hop_timeout_ms = 216;
+    int hop_timeout_ms = 20;
     int connect_timeout_ms = 10000;
     bool timing = false;
     std::vector<std::string> input_paths;

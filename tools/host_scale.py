@@ -50,7 +50,7 @@ def make_streams(n_streams: int, n_hops: int, seed: int = 7):
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16), sent
 
 
-def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = 100, timeout_s: float = 180.0):
+def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = None, timeout_s: float = 180.0):
     import resource
     soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
     if soft < n_streams + 256:
@@ -63,7 +63,7 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
     lst = os.path.join(tmp, "inputs.txt")
     with open(lst, "w") as f:
         f.write("\n".join(paths) + "\n")
-    cmd = [EXE] + DEEP + ["--print-bits", "--timing", f"--hop-timeout-ms={hop_timeout_ms}", f"--inputs-file={lst}"] + list(extra_args)
+    cmd = [EXE] + DEEP + ["--print-bits", "--timing", f"--inputs-file={lst}"] + ([f"--hop-timeout-ms={hop_timeout_ms}"] if hop_timeout_ms is not None else []) + list(extra_args)
     out_path, err_path = os.path.join(tmp, "stdout.txt"), os.path.join(tmp, "stderr.txt")
     with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
         proc = subprocess.Popen(cmd, stdout=fo, stderr=fe)
@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1024)
     ap.add_argument("--hops", type=int, default=20)
     ap.add_argument("--pace-ms", type=float, default=216.0)
-    ap.add_argument("--hop-timeout-ms", type=int, default=100)
+    ap.add_argument("--hop-timeout-ms", type=int, default=None, help="default: the decoder's own (20 ms)")
     a = ap.parse_args()
     print(json.dumps(run(a.streams, a.hops, a.pace_ms, hop_timeout_ms=a.hop_timeout_ms)), flush=True)
 
