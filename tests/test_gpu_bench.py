@@ -1,0 +1,43 @@
+"""-m gpu: bench.py itself - the line the driver records - through the N-rank launcher with the RCCL record gather (one rank on the
+one-GPU box) against the plain single-process run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2"] + extra, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_launcher_line_matches_the_plain_run():
+    plain = _bench(["--no-cpu-baseline"])
+    dist = _bench(["--gpus", "1", "--launcher", "--no-cpu-baseline"])
+    assert plain["n_gpus"] == dist["n_gpus"] == 1
+    assert plain["config"]["launch"] == "single process" and dist["config"]["launch"] == "torch.distributed.run"
+    g = dist["gather"]
+    assert g["backend"] == "nccl" and g["records_last_step"] == dist["decodes_last_step"] == plain["decodes_last_step"]
+    assert g["peak_records_per_rank"][0] <= g["capacity_per_rank"] and g["ms_per_step"] is not None
+    assert abs(dist["value"] / plain["value"] - 1.0) < 0.05, (dist["value"], plain["value"])
+    for line in (plain, dist):
+        assert line["config"]["softbits_gate_early"] is True and line["config"]["llr_store"] == "blocked/64"
+        assert line["roofline"]["kernel"] == "ldpc_kernel" and 0.0 < line["roofline"]["frac"] < 1.0
+        assert line["rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])
+
+
+def test_distributed_line_carries_the_cpu_baseline():
+    """What a driver's `bench.py --gpus N` prints must be gradeable: roofline, cpu_baseline and gather in one line."""
+    dist = _bench(["--gpus", "1", "--launcher"])
+    cb = dist["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "-march=native" in cb["flags"]
+    assert "gather" in dist and "roofline" in dist
