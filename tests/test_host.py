@@ -232,3 +232,87 @@ def test_unpack77_against_the_published_field_arithmetic(H):
         ok, text = _decode(H, t, b77)
         assert ok and text == want, (text, want)
     H.msk144host_table_free(t)
+
+
+# Literal 77-bit <-> text pairs for every message family the gate admits (decode_softbits.cpp:25-30): i3 = 0 with
+# n3 = 0 (free text) and 5 (telemetry), i3 = 1 and 2 (standard, with /R and /P, CQ nnn, CQ ABCD, DE/QRZ, grid / report / RRR / RR73 /
+# 73, the 3DA0 and 3X prefixes, 22-bit hashed calls), i3 = 4 (non-standard call + 12-bit hash) and i3 = 5 (two hashes, report, serial,
+# 6-character grid).  Frozen text constants: tests/golden/make_text_vectors.py printed them ONCE from the published field arithmetic
+# (QEX Jul/Aug 2020; not through tests/pack77.py, not through unpack77.cpp).  They are NOT WSJT-X output - WSJT-X is absent here - so the
+# text layer stays "conformance best-effort / parity unpinned"; the graded artefact is the 77-bit payload (--print-bits).
+# (calls that must have been heard before, 77 bits, text)
+TEXT_VECTORS = [
+    ("", "00000000000000000000000000100000010011011110111100011010100010100001100110001", "CQ K1ABC FN42"),
+    ("", "00001001101111011110001101010000011000010100100111011100000010000101011001001", "K1ABC W9XYZ EN37"),
+    ("", "00001100001010010011101110000000010011011110111100011010100111111010101000001", "W9XYZ K1ABC -11"),
+    ("", "00001001101111011110001101010000011000010100100111011100001111111010101010001", "K1ABC W9XYZ R-09"),
+    ("", "00001001101111011110001101010000011000010100100111011100000111111010111010001", "K1ABC W9XYZ +07"),
+    ("", "00001100001010010011101110000000010011011110111100011010100111111010010010001", "W9XYZ K1ABC RRR"),
+    ("", "00001001101111011110001101010000011000010100100111011100000111111010010011001", "K1ABC W9XYZ RR73"),
+    ("", "00001001101111011110001101010000011000010100100111011100000111111010010100001", "K1ABC W9XYZ 73"),
+    ("", "00001001101111011110001101010000011000010100100111011100000111111010010001001", "K1ABC W9XYZ"),
+    ("", "00000000000000000000000000000000010011011110111100011010100111111010010001001", "DE K1ABC"),
+    ("", "00000000000000000000000000010101101111011101011000101010000100010011010110001", "QRZ PA9XYZ JO22"),
+    ("", "00000000000000000000011111100000010010000110000010110011000011111000010011001", "CQ 123 G4ABC IO91"),
+    ("", "00000000000000000000000010100000010010000110000010110011000011111000010011001", "CQ 007 G4ABC IO91"),
+    ("", "00000000000000000100011011110110001010011111010110111100100101100111011101001", "CQ DX RA9YER MO05"),
+    ("", "00000000011000010101111110010000010011011110111100011010100010100001100110001", "CQ TEST K1ABC FN42"),
+    ("", "00000000000000000011111011000000010011011110111100011010100010100001100110001", "CQ A K1ABC FN42"),
+    ("", "00001001101111011110001101011000011000010100100111011100000010000101011001001", "K1ABC/R W9XYZ EN37"),
+    ("", "00001100001010010011101110000000010011011110111100011010111010100001100110001", "W9XYZ K1ABC/R R FN42"),
+    ("", "00001001000011000001011001101101101111011101011000101010000100010011010110010", "G4ABC/P PA9XYZ JO22"),
+    ("", "00001001000011000001011001100101101111011101011000101010011100010011010110010", "G4ABC PA9XYZ/P R JO22"),
+    ("", "00000000000000000000000000100001000110111010011000010001100100100011011101001", "CQ 3DA0XYZ KG53"),
+    ("", "00000000000000000000000000100110000101101001101010000100000011101111101011001", "CQ 3XY1A IJ39"),
+    ("", "00001001101111011110001101010100101110011011111110111110100000001110001110001", "K1ABC KH7Z AJ10"),
+    ("", "00000000000000000000000000100000011000010100100111011100000111111010001111001", "CQ W9XYZ RR99"),
+    ("", "00000000000000000000000000100000010011011110111100011010100000000000000000001", "CQ K1ABC AA00"),
+    ("", "00000011010100101011000010100000011000010100100111011100000111111010110000001", "<...> W9XYZ -03"),
+    ("PJ4/K1ABC", "00000011010100101011000010100000011000010100100111011100000111111010110000001", "<PJ4/K1ABC> W9XYZ -03"),
+    ("", "11110011000100000000000110100011101000110001000111001010101000000000010000100", "<...> PJ4/K1ABC"),
+    ("W9XYZ", "11110011000100000000000110100011101000110001000111001010101000000000010000100", "<W9XYZ> PJ4/K1ABC"),
+    ("W9XYZ", "11110011000100000000000110100011101000110001000111001010101000000000011100100", "PJ4/K1ABC <W9XYZ> RR73"),
+    ("W9XYZ", "11110011000100000000000000001110111011100011100111111010101100001001110010100", "<W9XYZ> YW18FIFA RRR"),
+    ("W9XYZ", "11110011000100000000000000001110111011100011100111111010101100001001111110100", "YW18FIFA <W9XYZ> 73"),
+    ("", "11110011000100000000000000001110111011100011100111111010101100001001110001100", "CQ YW18FIFA"),
+    ("", "11110011000100000000000110100011101000110001000111001010101000000000010001100", "CQ PJ4/K1ABC"),
+    ("G4ABC,PA9XYZ", "00101010110110000111101100010111111101000000001110100110101110000111001001101", "<G4ABC> <PA9XYZ> R 570007 JO22DB"),
+    ("G4ABC,PA9XYZ", "10000111101100101010110110010100110111100110100100100010111010110000000111101", "<PA9XYZ> <G4ABC> 591234 IO91NP"),
+    ("", "10000111101100101010110110010100110000000000000010000000000000000000000000101", "<...> <...> 520001 AA00AA"),
+    ("", "01100011111011011100111011100010101001001010111000000111111101010000000000000", "TNX BOB 73 GL"),
+    ("", "00000000000010001011010101101001100000011011100110110001010100000010010000000", "HELLO WORLD"),
+    ("", "00000000000000000000100010001001100110001001111010010110000111010001001000000", "1/2+3-4.5?"),
+    ("", "00000000000000000000000000000000000000000000000000000000000000000001011000000", "A"),
+    ("", "00100100011010001010110011110001001101010111100110111101111000000010010101000", "123456789ABCDEF012"),
+    ("", "00000000000000000000000000000000000000000000000000000001010101111001101101000", "ABCD"),
+    ("", "11111111111111111111111111111111111111111111111111111111111111111111111101000", "7FFFFFFFFFFFFFFFFF"),
+]
+
+HEARD_BY = {"W9XYZ": "CQ W9XYZ RR99", "G4ABC": "CQ 123 G4ABC IO91", "PA9XYZ": "QRZ PA9XYZ JO22", "PJ4/K1ABC": "CQ PJ4/K1ABC"}
+
+
+def test_literal_text_vectors(H):
+    by_text = {}
+    for heard, b, text in TEXT_VECTORS:
+        by_text.setdefault(text, b)
+    families = set()
+    for heard, b, text in TEXT_VECTORS:
+        assert len(b) == 77
+        t = H.msk144host_table_new()
+        for call in filter(None, heard.split(",")):
+            ok, _ = _decode(H, t, [int(c) for c in by_text[HEARD_BY[call]]])     # hear the call first: fills the 10/12/22-bit tables
+            assert ok
+        ok, got = _decode(H, t, [int(c) for c in b])
+        assert ok and got == text, (got, text)
+        families.add((int(b[74:77], 2), int(b[71:74], 2) if b[74:77] == "000" else None))
+        H.msk144host_table_free(t)
+    assert families == {(0, 0), (0, 5), (1, None), (2, None), (4, None), (5, None)}    # everything the gate admits except 0.2 (never sent on MSK144)
+
+
+def test_literal_vectors_match_the_generator():
+    """The constants above are what tests/golden/make_text_vectors.py prints today (guards against editing one side only)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_text_vectors", os.path.join(ROOT, "tests", "golden", "make_text_vectors.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert [tuple(v) for v in m.VECTORS] == [tuple(v) for v in TEXT_VECTORS]
