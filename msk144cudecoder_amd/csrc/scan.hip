@@ -24,8 +24,8 @@
 //     running maximum and its position per pattern (strict >: the lowest position keeps exact ties, as the reference's
 //     strict-> trees) - one compare, one max and one select per (position, pattern) and no cross-lane reduction, where
 //     the earlier form (positions across lanes, a 6-step DPP max + two ballots per 128 positions and pattern) spent half
-//     of the phase on reductions.  24 runs cover a slice; after a barrier they meet through the freed window buffer and
-//     one thread per (pattern, slice) takes the first strict maximum in position order;
+//     of the phase on reductions.  24 runs cover a slice = three aligned octets of lanes: each octet reduces in registers
+//     (3 DPP steps, first lane at the maximum wins) and one thread per (pattern, slice) merges three octets;
 //  4. xb = sqrt (correctly rounded) of the 21 x D slice maxima in parallel; then one wave, lane = 8*pattern + slot, runs the
 //     reference's 8-slot replacement rule in slice order (scan_kernel.cuh:276-353): arg-min over a pattern's 8 slots by
 //     three DPP min steps + ballot (lowest slot wins ties), conditional replace.
@@ -55,6 +55,7 @@ constexpr int kWrapPad = kSyncTaps - 1;
 constexpr int kRun = 11;
 constexpr int kRunsPerSlice = (kSlicePositions + kRun - 1) / kRun;  // 24
 static_assert(kScanSlices * kRunsPerSlice <= kScanThreads && kRun <= kWrapPad, "one run per lane; a run may cross the ring end inside the pad");
+static_assert(kRunsPerSlice % 8 == 0, "a slice is a whole number of aligned 8-lane groups (the octet merge of phase 3b)");
 static_assert(kScanThreads % 64 == 0 && kScanThreads * kOutPerThread >= kWindowSamples, "one in-place pass");
 
 struct ScanArgs
@@ -176,6 +177,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     __shared__ float2 s_buf[kWindowSamples + kWrapPad + kStreamPad];  // mixed window, later C[n] in place
     __shared__ float s_xb[kScanDepthMax][kScanSlices];        // per (pattern, slice): max |S| ...
     __shared__ uint32_t s_xpos[kScanDepthMax][kScanSlices];   // ... and its position
+    __shared__ float s_oct_v[kScanDepthMax][kScanThreads / 8];     // per (pattern, octet of runs): max |S|^2 ...
+    __shared__ uint32_t s_oct_pos[kScanDepthMax][kScanThreads / 8];  // ... and its position
 
     // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
     // contiguous range of tiles - the F tiles of a channel then share one L2 copy of its window.
@@ -346,35 +349,48 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for(int p = 0; p < D; p++) bidx[p] += start;
     }
-    __syncthreads();  // every wave has left the fold loop: nothing needs C any more
-
-    // ---- 3b. the 24 runs of a slice meet through the (now free) window buffer ----
+    // ---- 3b. the 24 runs of a slice meet: octet maxima in registers, three octets per slice through LDS ----
+    // Runs sit in lane order (tid = 24 slice + run), so a slice is exactly three aligned groups of eight lanes.  Each octet reduces
+    // its eight running maxima with three DPP steps and the FIRST lane holding the maximum (lowest position: the reference's
+    // strict-> trees keep the lowest position on exact ties) parks its (|S|^2, position) pair in s_oct - two masked stores per
+    // pattern instead of twelve unconditional ones per thread, and a three-element merge per (pattern, slice) instead of a
+    // 24-element one that kept six of the eight waves waiting.  s_oct is its own 4 KB of LDS, so no barrier is needed between the
+    // fold loop (which still reads the window buffer) and these stores.
     {
-        float* run_v = reinterpret_cast<float*>(s_buf);                               // [D][512]
-        uint32_t* run_pos = reinterpret_cast<uint32_t*>(s_buf) + kScanDepthMax * kScanThreads;
+        float omax[D + (D & 1)];
+#pragma unroll
+        for(int p = 0; p < D; p++) omax[p] = best[p];
+        if(D & 1) omax[D] = 0.0f;
+#pragma unroll
+        for(int p = 0; p < D; p += 2) oct_max2_f32(omax[p], omax[p + 1]);
+        const uint64_t lower = ((1ull << (lane & 7)) - 1ull) << (lane & 56);  // the lanes of my octet below me
+        const int oct = tid >> 3;
 #pragma unroll
         for(int p = 0; p < D; p++)
         {
-            run_v[p * kScanThreads + tid] = best[p];
-            run_pos[p * kScanThreads + tid] = bidx[p];
+            const bool is_max = best[p] == omax[p];
+            const uint64_t eq = __ballot(is_max);
+            if(is_max && (eq & lower) == 0ull)
+            {
+                s_oct_v[p][oct] = best[p];
+                s_oct_pos[p][oct] = bidx[p];
+            }
         }
     }
     __syncthreads();
 
-    // ---- 4a. slice maximum = first strict maximum over its runs in position order (the reference's strict-> trees keep the
-    //      lowest position on exact ties; the overlapping last run only repeats positions), xb = |S| (correctly rounded sqrt) ----
+    // ---- 4a. slice maximum = first strict maximum over its three octets in position order, xb = |S| (correctly rounded sqrt) ----
     for(int e = tid; e < D * kScanSlices; e += kScanThreads)
     {
         const int p = e / kScanSlices;
         const int sl = e - p * kScanSlices;
-        const float* rv = reinterpret_cast<const float*>(s_buf) + p * kScanThreads + sl * kRunsPerSlice;
-        const uint32_t* rp = reinterpret_cast<const uint32_t*>(s_buf) + (kScanDepthMax + p) * kScanThreads + sl * kRunsPerSlice;
-        float bv = rv[0];
-        uint32_t bp = rp[0];
-        for(int k = 1; k < kRunsPerSlice; k++)
+        float bv = s_oct_v[p][3 * sl];
+        uint32_t bp = s_oct_pos[p][3 * sl];
+#pragma unroll
+        for(int k = 1; k < kRunsPerSlice / 8; k++)
         {
-            const float v = rv[k];
-            const uint32_t q = rp[k];
+            const float v = s_oct_v[p][3 * sl + k];
+            const uint32_t q = s_oct_pos[p][3 * sl + k];
             if(v > bv)
             {
                 bv = v;
@@ -394,7 +410,20 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         const int pc = p < D ? p : 0;  // lanes of unused patterns shadow pattern 0 and store nothing
         float my_xb = 0.0f;            // reset(): pos 0, xb 0 (scan_kernel.cuh:78-82)
         uint32_t my_pos = 0u;
-        for(int s = 0; s < kScanSlices; s++)
+        // From the reset state the rule fills slots 0..7 in slice order as long as each of those slice maxima is > 0 (every
+        // stored xb is 0, the lowest-numbered slot still at 0 is the arg-min, and best > 0 replaces it): eight steps in one,
+        // unless some early maximum is 0 or NaN (all-zero or non-finite window) - then the serial rule runs from the start.
+        int s_first = 0;
+        {
+            const float mine = s_xb[pc][slot];
+            if(__ballot(mine > 0.0f) == ~0ull)
+            {
+                my_xb = mine;
+                my_pos = s_xpos[pc][slot];
+                s_first = kSlotsPerPattern;
+            }
+        }
+        for(int s = s_first; s < kScanSlices; s++)
         {
             const float best = s_xb[pc][s];
             const uint32_t best_pos = s_xpos[pc][s];

@@ -110,6 +110,27 @@ __device__ __forceinline__ float oct_min_f32(float v)
     return r;
 }
 
+// max over each aligned group of 8 lanes for two independent values at once (the chains interleave: one s_nop 0 per step completes
+// the two wait states a DPP read needs after the VALU write of its source).  NaN operands are ignored (v_max_f32 maxNum).
+__device__ __forceinline__ void oct_max2_f32(float& a, float& b)
+{
+    float ra, rb;
+    asm volatile("s_nop 4\n\t"
+                 "v_max_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "=&v"(ra), "=&v"(rb)
+                 : "v"(a), "v"(b));
+    a = ra;
+    b = rb;
+}
+
 // v + (its quad/row partners): after the four steps every lane of a 16-lane row holds the row sum, added
 // in the order lane^1, lane^2, other quad pair, other half - the reference's shuffle-tree association.
 __device__ __forceinline__ float row_sum_f32(float v)
