@@ -16,4 +16,5 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pmc -
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace -d $OUT/${TAG}_pmc -o sq1 --output-format csv -- $BENCH > /dev/null 2>> $OUT/${TAG}_pmc.err; echo "sq1 rc=$?"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/${TAG}_pmc -o sq2 --output-format csv -- $BENCH > /dev/null 2>> $OUT/${TAG}_pmc.err; echo "sq2 rc=$?"
 python3 tools/measure_extra.py > $OUT/${TAG}_measure_extra.txt 2> $OUT/${TAG}_measure_extra.err; echo "extra rc=$?"
+for n in 1024 4096; do timeout -k 5 200 python3 tools/host_scale.py --streams $n --hops 20 > $OUT/${TAG}_host_scale_${n}.json 2> $OUT/${TAG}_host_scale_${n}.err; echo "host scale $n rc=$?"; done
 ls $OUT/${TAG}_stats $OUT/${TAG}_pmc
