@@ -205,16 +205,15 @@ def cpu_baseline(windows: np.ndarray, budget_s: float = 12.0):
 
 
 def roofline_valu(valu, lds, dom):
-    """The roofline that binds: VALU issue (wave64 instructions per second per SIMD) and, for LDPC, the CU's LDS pipe.  `nominal`
-    prices every VALU instruction at the guide's 2 cycles; `priced` uses the per-class issue costs measured by
-    tools/ubench/valu_rates.hip (profiles/r02_valu_issue_microbench.txt: min/max/compare/select/DPP 4.3 cycles, exp/rcp/sqrt 8.2)
-    and is empirical.  None when the static counters are stale for these kernel sources."""
+    """The roofline that binds the dominant kernel: VALU issue (wave64 instructions per second per SIMD against the guide's 2 cycles
+    per instruction) and, for LDPC, the CU's single LDS pipe.  The nominal fraction understates the kernels: 30-45 % of their
+    instructions are half- or quarter-rate by nature (compare/select/DPP/max: ~4.3 cycles, exp/rcp/sqrt: ~8.2, measured by
+    tools/ubench/valu_rates.hip, profiles/r02_valu_issue_microbench.txt).  None when the static counters are stale for these sources."""
     if not valu or (dom + "_kernel") not in valu:
         return None
     k = dom + "_kernel"
     out = {"bound": "valu-issue", "kernel": k, "unit": "wave64 VALU instr/s", "achieved": valu[k]["achieved"], "peak": valu["peak"],
-           "frac_nominal": valu[k]["frac"], "frac_priced": valu[k].get("frac_priced"),
-           "priced_note": valu.get("priced_note"), "static": valu.get("static")}
+           "frac": valu[k]["frac"], "peak_note": valu.get("peak_note"), "static": valu.get("static")}
     if lds and k in lds:
         out["lds_pipe_busy"] = lds[k]["frac"]
         out["lds_conflict_share"] = lds[k]["conflict_share"]
