@@ -48,13 +48,14 @@ COUNTERS_FILE = os.path.join(ROOT, "profiles", "counters.json")
 
 
 def kernel_source_sha() -> str:
-    """Hash of the kernel sources' CODE (// comments and blank space dropped, so that rewording a comment does not orphan the
-    counters); profiles/counters.json records the one it was collected on, so stale static counters are never mixed with live
+    """Hash of the kernel sources' CODE - the .hip files and the headers they include (// comments and blank space dropped, so that
+    rewording a comment does not orphan the counters; the host-side msk144_api.cpp holds no device code or launch geometry and is
+    left out); profiles/counters.json records the one it was collected on, so stale static counters are never mixed with live
     timings."""
     csrc = os.path.join(ROOT, "msk144cudecoder_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h")):
             h.update(name.encode())
             for line in open(os.path.join(csrc, name), "r", encoding="utf-8"):
                 cut = line.find("//")

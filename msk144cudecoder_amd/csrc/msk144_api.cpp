@@ -239,6 +239,20 @@ int copy_windows_in(msk144_handle* h, const void* host_windows)
     return MSK144_OK;
 }
 
+// Long profiled runs (msk144hipdecoder --timing) never reach a synchronisation point: fold the spans whose end event has already
+// completed, oldest first, so that the pending list stays short without waiting for anything.
+void harvest_finished(msk144_handle* h)
+{
+    if(h->spans_pending.size() < 4096) return;
+    size_t done = 0;
+    while(done < h->spans_pending.size() && hipEventQuery(h->spans_pending[done].e1) == hipSuccess) done++;
+    if(done == 0) return;
+    std::vector<msk144_handle::Span> rest(h->spans_pending.begin() + static_cast<long>(done), h->spans_pending.end());
+    h->spans_pending.resize(done);
+    harvest_times(h);
+    h->spans_pending = std::move(rest);
+}
+
 int run_frontend(msk144_handle* h, const void* d_in)
 {
     ev_begin(h, MSK144_T_FRONTEND);
@@ -547,6 +561,7 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
         return fail(h, MSK144_ENOTRETAINED, "blocked staging runs softbits, index and LDPC together per channel block; a partial stage run needs llr_block_channels = channels");
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
+    if(h->profiling) harvest_finished(h);
     const DeviceStore cur = active_store(h);
     if(stages & MSK144_STAGE_SCAN)
     {
