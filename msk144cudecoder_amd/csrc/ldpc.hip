@@ -8,10 +8,12 @@
 //     no 11x38 byte scatter, no block reductions, no barriers;
 //   * tanh(-toc/2) is evaluated once per edge (384 per iteration, the reference recomputes 3840) with
 //     a 5-instruction exp2/rcp form (absolute error ~1.5e-7) and parked in a per-wave, bit-major LDS tile with M0-relative
-//     add-TID stores; lanes 0..37 gather their check's eleven factors (one per round of an edge colouring, so no gather ever
-//     conflicts: ldpc_layout.h), form the leave-one-out products with prefix/suffix products (27 multiplies instead of 110)
-//     and store them check-major with add-TID stores; each edge reads its own product back.  34 LDS instructions per
-//     iteration: the CU's LDS pipe charges an instruction 2.3-4.3 cycles whatever its active lanes, and four SIMDs share it;
+//     add-TID stores; lanes 0..37 gather their check's eleven factors, one per round (within a 32-lane group the real reads of a
+//     round hit 32 different banks and the constant-1.0 reads of the degree-10 checks a bank they leave free: ldpc_layout.h),
+//     form the leave-one-out products with prefix/suffix products (27 multiplies instead of 110) and store them check-major
+//     with add-TID stores at searched row residues; each edge reads its own product back.  34 LDS instructions and 2 bank-conflict
+//     cycles per iteration (PMC: profiles/counters.json): the CU's LDS pipe charges an instruction 2.3-4.3 cycles whatever its
+//     active lanes, and four SIMDs share it;
 //   * the piecewise-linear atanh keeps the reference's breakpoints and offsets; (z-c)/d is evaluated
 //     as z*(2/d) - c*(2/d) in one fma on the common piece, (z-c)*(2/d) on the rare upper pieces: within 1.6 ulp of the quotient;
 //   * CRC-13 runs as a wave-uniform bit-serial division only when all 38 checks are satisfied;
