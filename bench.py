@@ -189,7 +189,13 @@ def cpu_baseline(windows: np.ndarray, budget_s: float = 12.0):
     the -O2 build."""
     from oracle import oracle as orc  # test infrastructure: used here only as the timed CPU baseline
     cores = usable_cores()
-    o = orc.Oracle(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, threads=cores, library=orc.bench_lib())
+    flags = " ".join(orc.BENCH_FLAGS)
+    try:
+        library = orc.bench_lib()
+    except Exception as e:  # noqa: BLE001  (no compiler or a read-only tree on this host: time the parity build and say so)
+        library = None
+        flags = f"-O2 parity build of oracle/Makefile (the -O3 -march=native build failed here: {type(e).__name__})"
+    o = orc.Oracle(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, threads=cores, library=library)
     done = 0
     t0 = time.perf_counter()
     while True:
@@ -201,7 +207,7 @@ def cpu_baseline(windows: np.ndarray, budget_s: float = 12.0):
         if el + el / done > budget_s or done >= 64:
             break
     return {"value": done * o.total_items / el, "unit": "candidates/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
-            "flags": " ".join(orc.BENCH_FLAGS) + "; OpenMP over frequency hypotheses (scan, softbits) and gated candidates (BP)",
+            "flags": flags + "; OpenMP over frequency hypotheses (scan, softbits) and gated candidates (BP)",
             "sample": f"{done} window(s) of channel(s) 0..{done - 1}, step 0 (of {windows.shape[1]} channels), {el:.1f} s; exhaustive reference algorithm, not WSJT-X msk144spd"}
 
 
