@@ -110,6 +110,34 @@ def test_cli_multi_stream_equals_single_streams(tmp_path):
     assert err.count("Incomplete read error") == 3 and "3 input streams per GPU batch" in err
 
 
+def test_cli_multi_stream_iq_equals_single_streams(tmp_path):
+    """The same for --read-mode=2 (int8 I/Q, main.cu:334-380): four streams of different length as one batch per hop, partial
+    batches once the short ones have ended."""
+    rng = np.random.default_rng(81)
+    args = ["--read-mode=2", "--search-width=12", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2"]
+    files, singles = [], []
+    for i, n_hops in enumerate((3, 1, 0, 4)):
+        n = 5184 + n_hops * 2592
+        msg = pack77.pack_standard(("CQ", "K1ABC", "W9XYZ", "G4ABC")[i], ("K1ABC", "W9XYZ", "G4ABC", "PA9XYZ")[i], ("FN42", "EN37", "-07", "RR73")[i])
+        stream = synth.synth_iq(n, [synth.Ping(msg, 300 + 2000 * (i % 2), 6, 2.0 * (i - 1), 5.0, 0.2 * i)], 20.0, rng)
+        path = tmp_path / f"q{i}.s8"
+        path.write_bytes(stream.tobytes())
+        files.append(str(path))
+        rc, out, _ = _run(args, stream.tobytes())
+        assert rc == 0
+        singles.append([re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]])
+    assert sum(len(s) for s in singles) >= 4
+    rc, out, err = _run(args + ["--inputs=" + ",".join(files)], b"")
+    assert rc == 0, err
+    per_ch = {c: [] for c in range(4)}
+    for l in out.strip().split("\n")[:-1]:
+        m = re.match(r"^\*\*\*  ch=(\d+); (.*)$", l)
+        assert m, l
+        per_ch[int(m.group(1))].append("***  " + re.sub(r"date=\d{14}", "date=X", m.group(2)))
+    for c in range(4):
+        assert per_ch[c] == singles[c], c
+
+
 def test_cli_s1_stream_light_config(orc):
     """BASELINE configs[0]/[1] stand-in (demo/0001.wav is absent): the S1 functional stream at the README's
     'optimal scan' options, HIP program vs the oracle-driven CPU decoder, line for line."""
