@@ -54,6 +54,7 @@ void show_help(const char* prog)
     std::cout << " Additions of msk144hipdecoder (defaults in effect, as in the reference's code: search-width 200, scan-depth 4, nbadsync-threshold 1):" << std::endl;
     std::cout << "                   --inputs=F1,F2,...          Decode several raw streams (files or FIFOs) as one GPU batch per hop instead of stdin; lines then carry ch=<index>." << std::endl;
     std::cout << "                   --inputs-file=PATH          The same, one stream path per line (for hundreds of streams)." << std::endl;
+    std::cout << "                   --interleaved=N             Decode N streams that arrive on stdin as ONE interleaved stream - a block of N x 5184 samples (stream after stream), then blocks of N x 2592 per hop - as one GPU batch per hop; lines carry ch=<index>." << std::endl;
     std::cout << "                   --hop-timeout-ms=N          With --inputs: how long a batch waits for further streams once the first one has a hop ready (a batch costs what its streams cost, so small batches are cheap and keep the latency of each stream low). Default=20." << std::endl;
     std::cout << "                   --connect-timeout-ms=N      With --inputs: how long a FIFO may stay without a writer before it counts as ended. Default=10000." << std::endl;
     std::cout << "                   --skip-wav-header           Drop the first 44 bytes of every stream (the reference decodes a RIFF header as 22 samples). Default off." << std::endl;
@@ -169,6 +170,7 @@ int main(int argc, char* const argv[])
     bool skip_wav = false;
     int hop_timeout_ms = 20;
     int connect_timeout_ms = 10000;
+    int interleaved = 0;
     bool timing = false;
     std::vector<std::string> input_paths;
 
@@ -190,6 +192,7 @@ int main(int argc, char* const argv[])
                                            {"inputs-file", required_argument, 0, 0},
                                            {"timing", no_argument, 0, 0},
                                            {"connect-timeout-ms", required_argument, 0, 0},
+                                           {"interleaved", required_argument, 0, 0},
                                            {0, 0, 0, 0}};
     while(true)
     {
@@ -228,6 +231,7 @@ int main(int argc, char* const argv[])
         }
         case 16: timing = true; break;
         case 17: connect_timeout_ms = atoi(optarg); break;
+        case 18: interleaved = atoi(optarg); break;
         default: show_help(argv[0]); return 0;
         }
     }
@@ -250,9 +254,15 @@ int main(int argc, char* const argv[])
         return 0;
     }
 
-    const int nch = input_paths.empty() ? 1 : static_cast<int>(input_paths.size());
+    if(interleaved < 0 || (interleaved > 0 && !input_paths.empty()))
+    {
+        std::cerr << "--interleaved=N takes N >= 1 streams from stdin and excludes --inputs" << std::endl;
+        return 2;
+    }
+    const bool batched = interleaved > 0 || !input_paths.empty();
+    const int nch = interleaved > 0 ? interleaved : (input_paths.empty() ? 1 : static_cast<int>(input_paths.size()));
     opt.channels = nch;
-    opt.profile = timing && !input_paths.empty();
+    opt.profile = timing && batched;
     {
         // one descriptor per stream plus what the runtime opens: lift the soft limit when the hard limit allows
         rlimit lim{};
@@ -292,7 +302,7 @@ int main(int argc, char* const argv[])
               << std::endl;
     std::cerr << "msk144hipdecoder: " << F << " frequency hypotheses x " << D << " patterns x 8 = " << F * D * 8 << " candidates per window; HIP workgroups per window: scan "
               << F << " x 512, softbits " << F << " x 512, LDPC one wave per gated candidate" << std::endl;
-    if(nch > 1) std::cerr << "msk144hipdecoder: " << nch << " input streams per GPU batch, hop timeout " << hop_timeout_ms << " ms" << std::endl;
+    if(batched) std::cerr << "msk144hipdecoder: " << nch << " input streams per GPU batch" << (interleaved > 0 ? " (interleaved on stdin)" : "") << ", hop timeout " << hop_timeout_ms << " ms" << std::endl;
 
     const size_t sample_bytes = (opt.read_mode == 1) ? sizeof(int16_t) : 2 * sizeof(int8_t);
     const size_t win_bytes = MSK144_WINDOW_SAMPLES * sample_bytes;
@@ -300,7 +310,7 @@ int main(int argc, char* const argv[])
     const size_t unit = (opt.read_mode == 1) ? sizeof(int16_t) : sizeof(int8_t);  // the reference counts items of this size
     std::vector<std::vector<FilteredResult>> lines;
 
-    if(input_paths.empty())
+    if(!batched)
     {
         // ---- the reference's loop: one stream on stdin, blocking reads (main.cu:261-422) ----
         if(skip_wav)
@@ -347,7 +357,12 @@ int main(int argc, char* const argv[])
 
     // ---- several streams, one GPU batch per hop, non-blocking ingest, pipelined over two staging slots ----
     std::vector<Stream> st(nch);
-    for(int c = 0; c < nch; c++)
+    for(int c = 0; c < nch && interleaved > 0; c++)
+    {
+        st[c].pending.reserve(win_bytes);
+        st[c].window.assign(win_bytes, 0);
+    }
+    for(int c = 0; c < nch && interleaved == 0; c++)
     {
         // O_NONBLOCK: opening a FIFO whose writer has not arrived yet returns at once, and read() never parks the batch
         st[c].fd = open(input_paths[c].c_str(), O_RDONLY | O_NONBLOCK);
@@ -446,6 +461,8 @@ int main(int argc, char* const argv[])
 
     std::vector<pollfd> pfd(nch);
     std::vector<unsigned char> chunk(1 << 16);
+    std::vector<unsigned char> block;  // --interleaved: one hop of every stream
+    bool skip_block = skip_wav;
     Accumulator t_ingest;
     auto ingest_since = Clock::now();
     double ingest_busy_ms = 0.0;
@@ -459,7 +476,40 @@ int main(int argc, char* const argv[])
         // 1. drain whatever every open stream has, up to one hop each
         const auto d0 = Clock::now();
         int open_streams = 0, ready = 0;
-        for(int c = 0; c < nch; c++)
+        if(interleaved > 0 && !st[0].eof)
+        {
+            // one block per hop on stdin: the hop of stream 0, then of stream 1, ... (blocking read, like the reference's fread)
+            const size_t need = st[0].first ? win_bytes : half;
+            block.resize(need * nch);
+            if(skip_block)
+            {
+                unsigned char hdr[44];
+                if(fread(hdr, 1, sizeof(hdr), stdin) != sizeof(hdr)) std::cerr << "Incomplete read error. rc=0" << std::endl;
+                skip_block = false;
+            }
+            const size_t got = fread(block.data(), 1, block.size(), stdin);
+            if(got != block.size())
+            {
+                std::cerr << "Incomplete read error. rc=" << got / unit << std::endl;
+                for(Stream& s : st) s.eof = true;
+            }
+            else
+            {
+                const auto now = Clock::now();
+                for(int c = 0; c < nch; c++)
+                {
+                    st[c].pending.assign(block.begin() + static_cast<long>(need * c), block.begin() + static_cast<long>(need * (c + 1)));
+                    st[c].ready = true;
+                    st[c].ready_at = now;
+                }
+            }
+        }
+        for(int c = 0; c < nch && interleaved > 0; c++)
+        {
+            if(!st[c].eof) open_streams++;
+            if(st[c].ready) ready++;
+        }
+        for(int c = 0; c < nch && interleaved == 0; c++)
         {
             Stream& s = st[c];
             if(s.eof)
@@ -583,7 +633,7 @@ int main(int argc, char* const argv[])
         total_late += st[c].late;
         if(st[c].worst_ms > worst) worst = st[c].worst_ms;
         if(st[c].late) std::cerr << "ch=" << c << ": " << st[c].late << " of " << st[c].hops << " hops answered later than 210 ms (worst " << st[c].worst_ms << " ms)" << std::endl;
-        close(st[c].fd);
+        if(st[c].fd >= 0) close(st[c].fd);
     }
     std::cerr << "msk144hipdecoder: " << batches << " batches, " << total_hops << " stream hops, " << total_late << " late, worst latency " << worst << " ms" << std::endl;
     if(timing)

@@ -138,6 +138,35 @@ def test_cli_multi_stream_iq_equals_single_streams(tmp_path):
         assert per_ch[c] == singles[c], c
 
 
+def test_cli_interleaved_equals_single_streams():
+    """--interleaved=N (N streams as one interleaved stream on stdin, block per hop): every channel's lines are what the single-stream
+    program prints for that stream."""
+    rng = np.random.default_rng(82)
+    args = ["--search-width=16", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2"]
+    n_hops, streams, singles = 4, [], []
+    for i in range(3):
+        msg = pack77.pack_standard(("CQ", "K1ABC", "W9XYZ")[i], ("K1ABC", "W9XYZ", "G4ABC")[i], ("FN42", "-11", "RR73")[i])
+        x = synth.synth_audio(5184 + n_hops * 2592, [synth.Ping(msg, 1000 + 2500 * i, 6, 1500.0 + 2 * i, 5.0, 0.3 * i)], 1000.0, rng)
+        streams.append(x)
+        rc, out, _ = _run(args, x.tobytes())
+        assert rc == 0
+        singles.append([re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]])
+    assert all(len(s) >= 1 for s in singles)
+    blocks = [np.stack([s[:5184] for s in streams]).tobytes()]
+    for h in range(n_hops):
+        blocks.append(np.stack([s[5184 + h * 2592:5184 + (h + 1) * 2592] for s in streams]).tobytes())
+    rc, out, err = _run(args + ["--interleaved=3"], b"".join(blocks))
+    assert rc == 0, err
+    per_ch = {c: [] for c in range(3)}
+    for l in out.strip().split("\n")[:-1]:
+        m = re.match(r"^\*\*\*  ch=(\d+); (.*)$", l)
+        assert m, l
+        per_ch[int(m.group(1))].append("***  " + re.sub(r"date=\d{14}", "date=X", m.group(2)))
+    for c in range(3):
+        assert per_ch[c] == singles[c], c
+    assert "(interleaved on stdin)" in err
+
+
 def test_cli_s1_stream_light_config(orc):
     """BASELINE configs[0]/[1] stand-in (demo/0001.wav is absent): the S1 functional stream at the README's
     'optimal scan' options, HIP program vs the oracle-driven CPU decoder, line for line."""

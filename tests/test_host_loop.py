@@ -85,6 +85,24 @@ def test_inputs_file_and_stdin_single_stream(exe, tmp_path):
     assert "timing: wait for GPU + D2H (post thread)" in r.stderr.decode()
 
 
+def test_interleaved_stdin(exe):
+    """--interleaved=N: one block of N x 5184 samples, then N x 2592 per hop, stream after stream, on stdin."""
+    n, hops = 5, 6
+    streams = [marked_stream(hops, 300 * c) for c in range(n)]
+    blocks = [np.stack([s[:5184] for s in streams]).tobytes()]
+    for h in range(hops):
+        blocks.append(np.stack([s[5184 + h * 2592:5184 + (h + 1) * 2592] for s in streams]).tobytes())
+    r = subprocess.run([exe, f"--interleaved={n}"], input=b"".join(blocks) + b"\0" * 64, capture_output=True, timeout=60, env=dict(os.environ, MSK144_STUB_DECODE_MS="5"))
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    seen = windows_seen(r.stdout.decode(), n)
+    for c in range(n):
+        assert seen[c] == [(300 * c + k, 300 * c + k + 1) for k in range(hops + 1)], c
+    err = r.stderr.decode()
+    assert "Incomplete read error. rc=32" in err and f"{hops + 1} batches, {n * (hops + 1)} stream hops" in err
+    r = subprocess.run([exe, "--interleaved=2", "--inputs=a,b"], input=b"", capture_output=True, timeout=60)
+    assert r.returncode == 2 and "excludes --inputs" in r.stderr.decode()
+
+
 def test_fifos_late_writer_and_stalled_stream(exe, tmp_path):
     """Stream 1's writer connects 0.4 s after the decoder has opened the FIFO (read() returns 0 until then: NOT end of stream);
     stream 2 stalls for 0.5 s in the middle: the others keep going in batches of their own and nothing is lost or reordered."""
