@@ -427,7 +427,9 @@ def run_worker(args) -> int:
                        "analytic_method": 2, "llr_block_channels": getattr(be, "llr_block", None),
                        "llr_store": f"blocked/{llr_block}" if llr_block < channels else "retained",
                        "softbits_gate_early": bool(llr_block < channels), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
-                       "real_time_channels": value / be.K / (12000.0 / 2592.0)},
+                       "real_time_channels": value / be.K / (12000.0 / 2592.0),
+                       "real_time_channels_note": "GPU-only arithmetic (windows/s / 4.63); the stream decoder program itself was measured at 4096 real-time "
+                                                  "streams with 0 late hops on one MI355X (tools/host_scale.py, profiles/r03_host_scale_4096.json)"},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_launch, "avg_launch_ms": dom_ms, "launches_per_step": launches,
