@@ -16,6 +16,8 @@
  *                                                                 main.cu:477-484
  *   msk144_segment_power     the 8 segment powers SNRTracker::process_data sums from the analytic
  *                            window                               snr_tracker.cu:21-37, main.cu:388
+ *   msk144_hop_slot,         the 50 %-overlap window ring kept on the device: 2592 new samples per stream and hop travel, not
+ *   msk144_push_hops         5184-sample windows             main.cu:271-294, 337-359
  *   msk144_input_slot ..     the same hop, pipelined over two pinned staging slots (fread buffer -> H2D -> kernels ->
  *   msk144_fetch_wait        D2H of what the host loop consumes)  main.cu:261-422, 474-525
  *   msk144_dump_candidates   the raw ResultItem array (parity/debug)     result_keeper.cuh:17-32,123-130
@@ -209,6 +211,18 @@ int msk144_submit_slot(msk144_handle* h, int32_t slot);
  * the hop is sized for n_channels, so a partial batch - streams that lag sit it out - costs what its streams cost, not what the
  * handle's capacity costs.  Record channel numbers are positions in the slot. */
 int msk144_submit_slot_n(msk144_handle* h, int32_t slot, int32_t n_channels);
+/* Library-side hop ring (the reference's host keeps the 50 %-overlap window itself: main.cu:284-288 / 349-353 copy the second half
+ * over the first and fread 2592 new samples behind it; the first read fills all 5184, main.cu:271-283).  With these two calls the
+ * DEVICE keeps every stream's window: per hop the caller writes, for each of the n streams that have one, the 2592 new samples into
+ * hops[j], the stream's number (0 .. channels-1, ascending) into streams[j] and is_first[j] = 0 - or, for a stream's very first
+ * hop, its first 2592 samples into first_halves[j], the second 2592 into hops[j] and is_first[j] = 1.  msk144_push_hops copies only
+ * what the n hops need (half of what msk144_submit_slot_n copies), advances the rings of those streams on the device and runs the
+ * front end on their n windows; msk144_decode / msk144_fetch_async / msk144_fetch_wait follow as after msk144_submit_slot_n (record
+ * channel numbers are positions j).  A stream that is not listed keeps its window.  All four arrays are pinned, owned by the handle,
+ * sized for `channels` entries, allocated at the first msk144_hop_slot call; sample units as in msk144_submit_audio / _iq. */
+int msk144_hop_slot(msk144_handle* h, int32_t slot, void** hops /*[channels][2592 samples]*/, void** first_halves /*[channels][2592 samples]*/,
+                    int32_t** streams /*[channels]*/, uint8_t** is_first /*[channels]*/);
+int msk144_push_hops(msk144_handle* h, int32_t slot, int32_t n);
 int msk144_fetch_async(msk144_handle* h, int32_t slot);
 int msk144_fetch_wait(msk144_handle* h, int32_t slot, const msk144_result** records, int32_t* n, const float** seg_power /*[channels][8]*/);
 

@@ -24,6 +24,7 @@ SOURCES = [
     ("scan.hip", []),
     ("softbits.hip", []),
     ("index.hip", []),
+    ("hopring.hip", []),
     ("ldpc.hip", []),
     ("msk144_api.cpp", ["-x", "hip", "-ffp-contract=off"]),
 ]

@@ -71,12 +71,24 @@ struct msk144_handle
         int32_t copied = 0;                 // records covered by the asynchronous copy
         hipEvent_t done = nullptr;
         bool pending = false;
+        // hop-ring inputs (msk144_hop_slot), pinned, allocated on first use
+        void* hops = nullptr;          // [channels][half window]
+        void* first_halves = nullptr;  // [channels][half window]
+        int32_t* streams = nullptr;    // [channels]
+        uint8_t* is_first = nullptr;   // [channels]
     };
     Slot slots[MSK144_SLOTS];
     bool slots_ready = false;
     int cur_slot = 0;                        // the slot whose record list the next decode writes
     std::atomic<int32_t> last_total{0};      // record count of the last fetched hop: sizes the next asynchronous copy
     hipStream_t copy_stream = nullptr;       // remainder copies of msk144_fetch_wait (may run on a second thread)
+    // device side of the hop ring: every stream's current window, and the staging of one batch of hops
+    void* d_ring = nullptr;
+    void* d_hops = nullptr;
+    void* d_first = nullptr;
+    int32_t* d_streams = nullptr;
+    uint8_t* d_isfirst = nullptr;
+    bool ring_ready = false;
 
     std::string error;
 };
@@ -227,6 +239,35 @@ int ensure_slots(msk144_handle* h)
         if(!sl.done) HIP_TRY(h, hipEventCreateWithFlags(&sl.done, hipEventBlockingSync | hipEventDisableTiming));
     }
     h->slots_ready = true;
+    return MSK144_OK;
+}
+
+int ensure_ring(msk144_handle* h)
+{
+    if(h->ring_ready) return MSK144_OK;
+    int rc = ensure_slots(h);
+    if(rc != MSK144_OK) return rc;
+    const size_t nch = static_cast<size_t>(h->st.channels);
+    const size_t half = window_bytes(h) / 2;
+    uint8_t *ring = nullptr, *hops = nullptr, *first = nullptr;
+    if((rc = dev_alloc(h, &ring, nch * window_bytes(h))) != MSK144_OK) return rc;
+    if((rc = dev_alloc(h, &hops, nch * half)) != MSK144_OK) return rc;
+    if((rc = dev_alloc(h, &first, nch * half)) != MSK144_OK) return rc;
+    if((rc = dev_alloc(h, &h->d_streams, nch)) != MSK144_OK) return rc;
+    if((rc = dev_alloc(h, &h->d_isfirst, nch)) != MSK144_OK) return rc;
+    h->d_ring = ring;
+    h->d_hops = hops;
+    h->d_first = first;
+    HIP_TRY(h, hipMemsetAsync(h->d_ring, 0, nch * window_bytes(h), h->stream));
+    for(auto& sl : h->slots)
+    {
+        if((rc = host_alloc(h, &sl.hops, nch * half)) != MSK144_OK) return rc;
+        if((rc = host_alloc(h, &sl.first_halves, nch * half)) != MSK144_OK) return rc;
+        if((rc = host_alloc(h, reinterpret_cast<void**>(&sl.streams), nch * sizeof(int32_t))) != MSK144_OK) return rc;
+        if((rc = host_alloc(h, reinterpret_cast<void**>(&sl.is_first), nch)) != MSK144_OK) return rc;
+        std::memset(sl.is_first, 0, nch);
+    }
+    h->ring_ready = true;
     return MSK144_OK;
 }
 
@@ -453,6 +494,10 @@ void msk144_destroy(msk144_handle* h)
         if(sl.out) (void)hipHostFree(sl.out);
         if(sl.out_count) (void)hipHostFree(sl.out_count);
         if(sl.out_seg) (void)hipHostFree(sl.out_seg);
+        if(sl.hops) (void)hipHostFree(sl.hops);
+        if(sl.first_halves) (void)hipHostFree(sl.first_halves);
+        if(sl.streams) (void)hipHostFree(sl.streams);
+        if(sl.is_first) (void)hipHostFree(sl.is_first);
         if(sl.done) (void)hipEventDestroy(sl.done);
     }
     if(h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -702,6 +747,50 @@ int msk144_submit_slot_n(msk144_handle* h, int32_t slot, int32_t n_channels)
     h->active = n_channels;
     rc = copy_windows_in(h, h->slots[slot].in);
     return rc == MSK144_OK ? run_frontend(h, h->d_input) : rc;
+}
+
+int msk144_hop_slot(msk144_handle* h, int32_t slot, void** hops, void** first_halves, int32_t** streams, uint8_t** is_first)
+{
+    if(!h || !hops || !first_halves || !streams || !is_first || slot < 0 || slot >= MSK144_SLOTS) return fail(h, MSK144_EINVAL, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    int rc = ensure_ring(h);
+    if(rc != MSK144_OK) return rc;
+    msk144_handle::Slot& sl = h->slots[slot];
+    *hops = sl.hops;
+    *first_halves = sl.first_halves;
+    *streams = sl.streams;
+    *is_first = sl.is_first;
+    return MSK144_OK;
+}
+
+int msk144_push_hops(msk144_handle* h, int32_t slot, int32_t n)
+{
+    if(!h || slot < 0 || slot >= MSK144_SLOTS) return fail(h, MSK144_EINVAL, "bad argument");
+    if(!h->ring_ready) return fail(h, MSK144_ESTATE, "msk144_push_hops before msk144_hop_slot");
+    if(n < 1 || n > h->st.channels) return fail(h, MSK144_EINVAL, "n must be 1..channels");
+    msk144_handle::Slot& sl = h->slots[slot];
+    if(sl.pending) return fail(h, MSK144_ESTATE, "slot submitted again before its results were fetched (msk144_fetch_wait)");
+    bool any_first = false;
+    for(int32_t j = 0; j < n; j++)
+    {
+        if(sl.streams[j] < 0 || sl.streams[j] >= h->st.channels || (j > 0 && sl.streams[j] <= sl.streams[j - 1]))
+            return fail(h, MSK144_EINVAL, "streams must be ascending stream numbers below channels");
+        any_first = any_first || sl.is_first[j] != 0;
+    }
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    h->call_id++;
+    h->cur_slot = slot;
+    h->active = n;
+    const size_t half = window_bytes(h) / 2;
+    ev_begin(h, MSK144_T_H2D);
+    hipError_t e = hipMemcpyAsync(h->d_hops, sl.hops, half * n, hipMemcpyHostToDevice, h->stream);
+    if(e == hipSuccess && any_first) e = hipMemcpyAsync(h->d_first, sl.first_halves, half * n, hipMemcpyHostToDevice, h->stream);
+    if(e == hipSuccess) e = hipMemcpyAsync(h->d_streams, sl.streams, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream);
+    if(e == hipSuccess) e = hipMemcpyAsync(h->d_isfirst, sl.is_first, n, hipMemcpyHostToDevice, h->stream);
+    ev_end(h, MSK144_T_H2D);
+    if(e != hipSuccess) return fail(h, MSK144_EHIP, std::string("msk144_push_hops: ") + hipGetErrorString(e));
+    launch_hop_ring(h->d_ring, h->d_hops, h->d_first, h->d_streams, h->d_isfirst, h->d_input, n, h->stream);
+    return run_frontend(h, h->d_input);
 }
 
 int msk144_fetch_async(msk144_handle* h, int32_t slot)

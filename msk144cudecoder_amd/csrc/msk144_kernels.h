@@ -66,6 +66,10 @@ void launch_frontend_audio(const DeviceStore& st, const int16_t* d_in, int analy
                            hipStream_t stream);
 void launch_frontend_iq(const DeviceStore& st, const int8_t* d_in, hipStream_t stream);
 
+// device-side window ring of every stream (hopring.hip): ring[streams[j]] advances by the hop at position j (or is filled from
+// first_halves[j] + hops[j] when is_first[j]); windows[j] = the stream's new window.  Halves and windows in raw input bytes.
+void launch_hop_ring(void* ring, const void* hops, const void* first_halves, const int32_t* streams, const uint8_t* is_first, void* windows, int n, hipStream_t stream);
+
 // hot kernels
 void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t stream);
 void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t stream);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "msk144_submit_analytic", "msk144_decode", "msk144_decode_stages", "msk144_synchronize", "msk144_results",
     "msk144_result_count", "msk144_results_device", "msk144_set_channel_base", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
-    "msk144_input_slot", "msk144_submit_slot", "msk144_submit_slot_n", "msk144_fetch_async", "msk144_fetch_wait",
+    "msk144_input_slot", "msk144_submit_slot", "msk144_submit_slot_n", "msk144_fetch_async", "msk144_fetch_wait", "msk144_hop_slot", "msk144_push_hops",
 )
 
 
@@ -104,6 +104,8 @@ def load_library(path: Optional[str] = None):
     L.msk144_input_slot.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.msk144_submit_slot.argtypes = [vp, i32]
     L.msk144_submit_slot_n.argtypes = [vp, i32, i32]
+    L.msk144_hop_slot.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.msk144_push_hops.argtypes = [vp, i32, i32]
     L.msk144_fetch_async.argtypes = [vp, i32]
     L.msk144_fetch_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp)]
     if path is None:
@@ -233,6 +235,22 @@ class HipDecoder:
     def submit_slot(self, slot: int, n_channels: int = 0):
         """n_channels > 0: the hop covers only the first n_channels windows of the slot."""
         self._chk(self.L.msk144_submit_slot_n(self.h, slot, n_channels) if n_channels else self.L.msk144_submit_slot(self.h, slot))
+
+    def hop_slot(self, slot: int):
+        """(hops, first_halves, streams, is_first): numpy views of the slot's pinned hop-ring inputs - hops and first_halves as
+        [channels][2592] int16 or [channels][2*2592] int8, streams int32[channels], is_first uint8[channels]."""
+        p = [C.c_void_p() for _ in range(4)]
+        self._chk(self.L.msk144_hop_slot(self.h, slot, *[C.byref(x) for x in p]))
+        half = 5184  # bytes of half a window in both read modes
+        dt = np.int8 if self.read_mode == 2 else np.int16
+        hops = np.frombuffer((C.c_uint8 * (half * self.channels)).from_address(p[0].value), dtype=dt).reshape(self.channels, -1)
+        first = np.frombuffer((C.c_uint8 * (half * self.channels)).from_address(p[1].value), dtype=dt).reshape(self.channels, -1)
+        streams = np.frombuffer((C.c_int32 * self.channels).from_address(p[2].value), dtype=np.int32)
+        is_first = np.frombuffer((C.c_uint8 * self.channels).from_address(p[3].value), dtype=np.uint8)
+        return hops, first, streams, is_first
+
+    def push_hops(self, slot: int, n: int):
+        self._chk(self.L.msk144_push_hops(self.h, slot, n))
 
     def fetch_async(self, slot: int):
         self._chk(self.L.msk144_fetch_async(self.h, slot))

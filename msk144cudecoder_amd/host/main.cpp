@@ -127,7 +127,6 @@ struct Stream
     std::vector<unsigned char> pending;
     bool ready = false;           // a complete hop sits in `pending`
     Clock::time_point ready_at;
-    std::vector<unsigned char> window;  // the stream's current 5184-sample window (main.cu:269-294: fill, then shift by half)
     // deadline accounting (owned by the post-processing thread)
     long hops = 0, late = 0;
     long long worst_ms = 0;
@@ -137,7 +136,8 @@ struct Stream
 struct Batch
 {
     int slot = 0;
-    std::vector<int> streams;                  // the streams that have a hop in this batch, ascending
+    int n = 0;                                 // streams that have a hop in this batch
+    std::vector<int> streams;                  // which ones, ascending
     std::vector<Clock::time_point> ready_at;  // when each of them had its hop complete
     Clock::time_point go;                      // batch released by the policy
     double assemble_ms = 0.0, submit_ms = 0.0;
@@ -360,7 +360,6 @@ int main(int argc, char* const argv[])
     for(int c = 0; c < nch && interleaved > 0; c++)
     {
         st[c].pending.reserve(win_bytes);
-        st[c].window.assign(win_bytes, 0);
     }
     for(int c = 0; c < nch && interleaved == 0; c++)
     {
@@ -373,16 +372,14 @@ int main(int argc, char* const argv[])
         }
         st[c].skip = skip_wav ? 44 : 0;
         st[c].pending.reserve(win_bytes);
-        st[c].window.assign(win_bytes, 0);
         struct stat sb{};
         st[c].fifo = fstat(st[c].fd, &sb) == 0 && S_ISFIFO(sb.st_mode);
     }
     const auto opened_at = Clock::now();
-    unsigned char* stage[WindowDecoder::kSlots];
+    WindowDecoder::HopStage stage[WindowDecoder::kSlots];
     for(int k = 0; k < WindowDecoder::kSlots; k++)
     {
-        stage[k] = static_cast<unsigned char*>(dec.stage(k));  // pinned, owned by the library handle
-        if(!stage[k])
+        if(!dec.hop_stage(k, stage[k]))  // pinned, owned by the library handle; the stream windows themselves live on the device
         {
             std::cerr << "msk144hip: " << dec.error() << std::endl;
             return 2;
@@ -586,28 +583,33 @@ int main(int argc, char* const argv[])
             b.slot = free_slots.front();
             free_slots.pop_front();
         }
-        // 4. advance the window of every stream that has a hop (main.cu:284-288) and pack those windows back to back into the
-        // pinned slot; streams without a hop sit this batch out and cost nothing on the GPU
+        // 4. hand the new samples of every stream that has a hop to the library, packed back to back in the pinned slot: 2592 per
+        // stream (all 5184 of a stream's first hop).  The 50 %-overlap window of each stream (main.cu:284-288) lives on the device
+        // (msk144_push_hops); streams without a hop sit this batch out and cost nothing on the GPU
         const auto a0 = Clock::now();
+        WindowDecoder::HopStage& hs = stage[b.slot];
         for(int c = 0; c < nch; c++)
         {
             Stream& s = st[c];
             if(!s.ready) continue;
-            if(s.first) memcpy(s.window.data(), s.pending.data(), win_bytes);
-            else
+            const size_t j = b.streams.size();
+            if(s.first)
             {
-                memcpy(s.window.data(), s.window.data() + half, half);
-                memcpy(s.window.data() + half, s.pending.data(), half);
+                memcpy(hs.first_halves + half * j, s.pending.data(), half);
+                memcpy(hs.hops + half * j, s.pending.data() + half, half);
             }
-            memcpy(stage[b.slot] + win_bytes * b.streams.size(), s.window.data(), win_bytes);
+            else memcpy(hs.hops + half * j, s.pending.data(), half);
+            hs.streams[j] = c;
+            hs.is_first[j] = s.first ? 1 : 0;
             b.streams.push_back(c);
             b.ready_at.push_back(s.ready_at);
             s.first = false;
             s.pending.clear();
             s.ready = false;
         }
+        b.n = static_cast<int>(b.streams.size());
         const auto a1 = Clock::now();
-        if(!dec.submit(b.slot, b.streams))
+        if(!dec.submit_hops(b.slot, b.n))
         {
             std::cerr << "msk144hip: " << dec.error() << std::endl;
             return finish(2);
@@ -644,7 +646,7 @@ int main(int argc, char* const argv[])
         };
         fprintf(stderr, "msk144hipdecoder timing: %d streams, %ld batches in %.2f s wall; per batch (host wall time):\n", nch, batches, wall_s);
         row("ingest (read syscalls, all streams)", t_ingest);
-        row("assemble windows in pinned slot", t_assemble);
+        row("copy new hops into pinned slot", t_assemble);
         row("submit (3 asynchronous calls)", t_submit);
         row("wait for GPU + D2H (post thread)", t_wait);
         row("post-processing (text, SNR, filter)", t_post);

@@ -97,6 +97,35 @@ void* WindowDecoder::stage(int slot)
     return p;
 }
 
+bool WindowDecoder::hop_stage(int slot, HopStage& out)
+{
+    void *hops = nullptr, *first = nullptr;
+    if(msk144_hop_slot(handle_, slot, &hops, &first, &out.streams, &out.is_first) != MSK144_OK)
+    {
+        error_ = msk144_last_error(handle_);
+        return false;
+    }
+    out.hops = static_cast<unsigned char*>(hops);
+    out.first_halves = static_cast<unsigned char*>(first);
+    return true;
+}
+
+bool WindowDecoder::submit_hops(int slot, int n)
+{
+    HopStage hs;
+    if(!hop_stage(slot, hs)) return false;
+    streams_[slot].assign(hs.streams, hs.streams + n);
+    int rc = msk144_push_hops(handle_, slot, n);
+    if(rc == MSK144_OK) rc = msk144_decode(handle_);
+    if(rc == MSK144_OK) rc = msk144_fetch_async(handle_, slot);
+    if(rc != MSK144_OK)
+    {
+        error_ = msk144_last_error(handle_);
+        return false;
+    }
+    return true;
+}
+
 bool WindowDecoder::submit(int slot, const std::vector<int>& streams)
 {
     streams_[slot] = streams;

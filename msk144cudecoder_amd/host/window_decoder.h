@@ -93,6 +93,18 @@ public:
     // and the GPU work, the copies and the results of the hop are sized for that many windows - a stream that has no hop this
     // time costs nothing.  lines[c] is indexed by STREAM.
     static constexpr int kSlots = MSK144_SLOTS;
+    // The slot's pinned hop-ring inputs (msk144_hop_slot): the device keeps every stream's 50 %-overlap window, so a hop ships
+    // 2592 new samples per stream - entry j: hops (and, for a stream's first hop, first_halves) at j * half-window bytes,
+    // streams[j] = the stream's number (ascending), is_first[j].
+    struct HopStage
+    {
+        unsigned char* hops = nullptr;
+        unsigned char* first_halves = nullptr;
+        int32_t* streams = nullptr;
+        uint8_t* is_first = nullptr;
+    };
+    bool hop_stage(int slot, HopStage& out);
+    bool submit_hops(int slot, int n);  // the first n entries of the slot's hop stage
     void* stage(int slot);
     bool submit(int slot, const std::vector<int>& streams);
     bool collect(int slot, std::vector<std::vector<FilteredResult>>& lines, HopTiming* timing = nullptr);

@@ -18,6 +18,11 @@ struct msk144_handle
 {
     msk144_params p;
     std::vector<int16_t> in[MSK144_SLOTS];
+    // hop ring (msk144_hop_slot / msk144_push_hops): per-slot inputs and every stream's window
+    std::vector<int16_t> hops[MSK144_SLOTS], first_halves[MSK144_SLOTS];
+    std::vector<int32_t> streams[MSK144_SLOTS];
+    std::vector<uint8_t> is_first[MSK144_SLOTS];
+    std::vector<int16_t> ring;
     std::vector<msk144_result> out[MSK144_SLOTS];
     std::vector<float> seg[MSK144_SLOTS];
     std::future<void> job[MSK144_SLOTS];
@@ -110,6 +115,58 @@ int msk144_submit_slot_n(msk144_handle* h, int32_t s, int32_t n)
 }
 
 int msk144_submit_slot(msk144_handle* h, int32_t s) { return msk144_submit_slot_n(h, s, h->p.channels); }
+
+int msk144_hop_slot(msk144_handle* h, int32_t s, void** hops, void** first_halves, int32_t** streams, uint8_t** is_first)
+{
+    if(s < 0 || s >= MSK144_SLOTS) return MSK144_EINVAL;
+    const size_t nch = static_cast<size_t>(h->p.channels);
+    if(h->ring.empty())
+    {
+        h->ring.assign(nch * MSK144_WINDOW_SAMPLES, 0);
+        for(int k = 0; k < MSK144_SLOTS; k++)
+        {
+            h->hops[k].assign(nch * MSK144_HOP_SAMPLES, 0);
+            h->first_halves[k].assign(nch * MSK144_HOP_SAMPLES, 0);
+            h->streams[k].assign(nch, 0);
+            h->is_first[k].assign(nch, 0);
+            h->in[k].assign(nch * MSK144_WINDOW_SAMPLES, 0);
+        }
+    }
+    *hops = h->hops[s].data();
+    *first_halves = h->first_halves[s].data();
+    *streams = h->streams[s].data();
+    *is_first = h->is_first[s].data();
+    return MSK144_OK;
+}
+
+// the device-side ring, on the CPU: advance the listed streams' windows and lay them out as the compact batch of the slot
+int msk144_push_hops(msk144_handle* h, int32_t s, int32_t n)
+{
+    if(h->ring.empty() || n < 1 || n > h->p.channels) return MSK144_EINVAL;
+    if(h->pending[s])
+    {
+        h->error = "stub: slot submitted again before its results were fetched";
+        return MSK144_ESTATE;
+    }
+    const size_t half = MSK144_HOP_SAMPLES;
+    for(int j = 0; j < n; j++)
+    {
+        const int c = h->streams[s][j];
+        if(c < 0 || c >= h->p.channels || (j > 0 && c <= h->streams[s][j - 1]))
+        {
+            h->error = "stub: streams must be ascending";
+            return MSK144_EINVAL;
+        }
+        int16_t* r = h->ring.data() + static_cast<size_t>(c) * MSK144_WINDOW_SAMPLES;
+        if(h->is_first[s][j]) std::memcpy(r, h->first_halves[s].data() + j * half, half * sizeof(int16_t));
+        else std::memmove(r, r + half, half * sizeof(int16_t));
+        std::memcpy(r + half, h->hops[s].data() + j * half, half * sizeof(int16_t));
+        std::memcpy(h->in[s].data() + static_cast<size_t>(j) * MSK144_WINDOW_SAMPLES, r, MSK144_WINDOW_SAMPLES * sizeof(int16_t));
+    }
+    h->cur = s;
+    h->active[s] = n;
+    return MSK144_OK;
+}
 
 int msk144_decode(msk144_handle*) { return MSK144_OK; }
 

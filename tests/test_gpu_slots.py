@@ -188,3 +188,62 @@ def test_partial_hop_covers_only_its_streams(hip):
         with pytest.raises(hip.Msk144Error):
             d.submit_slot(0, capacity + 1)
     assert len(full) > 50
+
+
+@pytest.mark.parametrize("read_mode", [1, 2])
+def test_device_side_hop_ring_equals_host_windows(hip, read_mode):
+    """msk144_hop_slot / msk144_push_hops: the device keeps every stream's 50 %-overlap window (main.cu:271-294, 337-359); shipping
+    2592 new samples per stream and hop must give exactly the records of shipping the windows a host-side ring would hold - for
+    streams that skip hops, for first hops in the middle of a run, on both slots, in both read modes."""
+    channels, n_hops = 6, 5
+    rng = np.random.default_rng(31 + read_mode)
+    per = 1 if read_mode == 1 else 2
+    cfg = dict(CFG, center=1500.0 if read_mode == 1 else 0.0)
+    total = 5184 + n_hops * 2592
+    streams = []
+    for c in range(channels):
+        pings = [synth.Ping(synth.random_message(rng), int(rng.integers(0, total - 6 * 864)), 6, cfg["center"] + float(rng.uniform(-20, 20)), 4.0, float(rng.uniform(0, 6)))]
+        streams.append(synth.synth_audio(total, pings, 1000.0, rng) if read_mode == 1 else synth.synth_iq(total, pings, 20.0, rng))
+    # which streams have a hop in which batch; stream 4 joins late (its first hop is batch 2)
+    schedule = [[0, 1, 2, 3, 5], [0, 2, 3, 5], [1, 2, 4], [0, 1, 2, 3, 4, 5], [2, 4, 5], [0, 1, 3]]
+    consumed = [0] * channels                      # samples of each stream handed over so far
+    window = [None] * channels                     # the host-side ring, for the expected records
+    H = 2592 * per
+    got, want = [], []
+    with hip.HipDecoder(channels=channels, read_mode=read_mode, max_results=1 << 16, **cfg) as d, \
+            hip.HipDecoder(channels=channels, read_mode=read_mode, max_results=1 << 16, **cfg) as ref:
+        for b, members in enumerate(schedule):
+            s = b % 2
+            hops, first_halves, ids, is_first = d.hop_slot(s)
+            for j, c in enumerate(members):
+                x = streams[c]
+                if consumed[c] == 0:
+                    first_halves[j, :] = x[:H]
+                    hops[j, :] = x[H:2 * H]
+                    window[c] = x[:2 * H].copy()
+                    consumed[c] = 2 * H
+                    is_first[j] = 1
+                else:
+                    hops[j, :] = x[consumed[c]:consumed[c] + H]
+                    window[c] = np.concatenate([window[c][H:], x[consumed[c]:consumed[c] + H]])
+                    consumed[c] += H
+                    is_first[j] = 0
+                ids[j] = c
+            d.push_hops(s, len(members))
+            d.decode()
+            d.fetch_async(s)
+            if b >= 1:
+                got.append(d.fetch_wait(1 - s))
+            ref.input_slot(0)[:len(members)] = np.stack([window[c] for c in members])
+            ref.submit_slot(0, len(members))
+            ref.decode()
+            ref.fetch_async(0)
+            want.append(ref.fetch_wait(0))
+        got.append(d.fetch_wait((len(schedule) - 1) % 2))
+        with pytest.raises(hip.Msk144Error):
+            d.hop_slot(0)[2][:2] = [3, 1]                                   # not ascending
+            d.push_hops(0, 2)
+    assert sum(len(r) for r, _ in want) > 10
+    for (r0, p0), (r1, p1), members in zip(want, got, schedule):
+        assert r0.tobytes() == r1.tobytes()
+        assert np.array_equal(p0[:len(members)].view(np.uint32), p1[:len(members)].view(np.uint32))
