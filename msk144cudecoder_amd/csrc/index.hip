@@ -49,30 +49,64 @@ __global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st
     const size_t off = static_cast<size_t>(ch) * st.K;
     const int32_t* __restrict__ nbad = st.nbadsync + off;
     int32_t* __restrict__ out = st.idx + off;
-    int base = 0;
-    // The kernel is a chain of global-load latencies (one workgroup per channel, 24 steps for a deep window): fetch eight steps'
-    // worth of flags at once so that a latency is paid per 8192 items, not per 1024.
-    constexpr int kBatch = 8;
-    for(int k0 = 0; k0 < st.K; k0 += kBatch * kIdxThreads)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // Every wave owns one contiguous range of items (a multiple of 64), so the ascending order of the list is wave order, then
+    // group order inside the wave: pass 1 counts the range, ONE barrier publishes the sixteen counts, pass 2 re-reads the flags
+    // (L2 hits) and writes.  The earlier form walked the channel 1024 items at a time with two barriers per step - 48 barriers for a
+    // deep window, 19 us per launch; this one is a chain of two load latencies.
+    const int per_wave = ((st.K + kIdxThreads - 1) / kIdxThreads) * 64;
+    const int k_begin = wave * per_wave;
+    const int k_end = k_begin + per_wave < st.K ? k_begin + per_wave : st.K;
+    constexpr int kBatch = 8;  // loads in flight per lane
+    int count = 0;
+    for(int k0 = k_begin; k0 < k_end; k0 += kBatch * 64)
     {
         int32_t nb[kBatch];
 #pragma unroll
         for(int j = 0; j < kBatch; j++)
         {
-            const int k = k0 + j * kIdxThreads + threadIdx.x;
-            nb[j] = k < st.K ? nbad[k] : 0x7fffffff;
+            const int k = k0 + j * 64 + lane;
+            nb[j] = k < k_end ? nbad[k] : 0x7fffffff;
         }
 #pragma unroll
         for(int j = 0; j < kBatch; j++)
         {
-            const int k = k0 + j * kIdxThreads + threadIdx.x;
-            if(k0 + j * kIdxThreads >= st.K) break;  // workgroup-uniform
-            if(k < st.K) st.dec_flag[off + k] = 0;  // clear_result (result_keeper.cuh:61-73) for the fields LDPC may set
-            const int slot = ordered_slot(nb[j] <= st.nbadsync_threshold, base, s_wave_count);
-            if(slot >= 0) out[slot] = k;
+            const int k = k0 + j * 64 + lane;
+            if(k < k_end) st.dec_flag[off + k] = 0;  // clear_result (result_keeper.cuh:61-73) for the fields LDPC may set
+            count += __popcll(__ballot(nb[j] <= st.nbadsync_threshold));
         }
     }
-    if(threadIdx.x == 0) st.n_idx[ch] = base;
+    if(lane == 0) s_wave_count[wave] = count;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for(int w = 0; w < kIdxWaves; w++)
+    {
+        const int c = s_wave_count[w];
+        if(w < wave) base += c;
+        total += c;
+    }
+    for(int k0 = k_begin; k0 < k_end; k0 += kBatch * 64)
+    {
+        int32_t nb[kBatch];
+#pragma unroll
+        for(int j = 0; j < kBatch; j++)
+        {
+            const int k = k0 + j * 64 + lane;
+            nb[j] = k < k_end ? nbad[k] : 0x7fffffff;
+        }
+#pragma unroll
+        for(int j = 0; j < kBatch; j++)
+        {
+            const int k = k0 + j * 64 + lane;
+            const bool flag = nb[j] <= st.nbadsync_threshold;
+            const unsigned long long m = __ballot(flag);
+            if(flag) out[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            base += __popcll(m);
+        }
+    }
+    if(threadIdx.x == 0) st.n_idx[ch] = total;
 }
 
 // ---- collect: accepted decodes -> compact msk144_result records, ordered by (channel, item) ----
