@@ -4,7 +4,7 @@ BASELINE configs[2] size: for every staged window of the bench inputs, the 1024-
 compared with the oracle exactly as tests/test_gpu_full.py does (tests/parity.py: records == accepted candidates of the channel's
 dump, dump vs decode_window stage by stage with verified near-ties only).  TEST INFRASTRUCTURE: uses oracle/ and tests/parity.py.
 
-    python tools/production_soak.py [--channels-per-window 48]   ->  one JSON line
+    python tests/soak_production.py [--channels-per-window 48]   ->  one JSON line
 """
 import argparse
 import json
