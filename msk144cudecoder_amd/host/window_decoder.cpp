@@ -21,10 +21,10 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
     p.channels = opt.channels < 1 ? 1 : opt.channels;
     opt_.channels = p.channels;
     p.device = opt.device;
-    // Compact-list capacity: a strong ping is accepted by many of its candidates (neighbouring bins, patterns, slots), 256 per
-    // channel on average is far beyond anything a real band produces; the library clamps to channels * items, and a list that did
+    // Compact-list capacity: a strong ping is accepted by many of its candidates (neighbouring bins, patterns, slots); 256 per
+    // channel on average plus 131072 is far beyond anything a real band produces; the library clamps to channels * items, and a list that did
     // overflow is an error (MSK144_EOVERFLOW), never a silent truncation.
-    const long long cap = 256ll * p.channels + 4096;
+    const long long cap = 256ll * p.channels + 131072;  // a one-stream handle can hold every candidate of the widest search grid
     p.max_results = cap > 0x7fffffff ? 0x7fffffff : static_cast<int32_t>(cap);
     if(msk144_create(&p, &handle_) != MSK144_OK)
     {
