@@ -167,6 +167,31 @@ def test_cli_interleaved_equals_single_streams():
     assert "(interleaved on stdin)" in err
 
 
+def test_cli_silent_stream_among_live_ones(tmp_path):
+    """A muted channel (all-zero samples: rms 0 -> the reference's unguarded 1/0 normalisation) in a batch must not
+    disturb the other streams or hang the batch: it prints nothing, the others print what they print alone."""
+    rng = np.random.default_rng(83)
+    args = ["--search-width=16", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2"]
+    n = 5184 + 3 * 2592
+    live = synth.synth_audio(n, [synth.Ping(pack77.pack_standard("CQ", "K1ABC", "FN42"), 2000, 6, 1502.0, 6.0, 0.2)], 1000.0, rng)
+    files = []
+    for i, x in enumerate((live, np.zeros(n, dtype=np.int16), live)):
+        path = tmp_path / f"z{i}.s16"
+        path.write_bytes(x.tobytes())
+        files.append(str(path))
+    rc, alone, _ = _run(args, live.tobytes())
+    want = [re.sub(r"date=\d{14}", "date=X", l) for l in alone.strip().split("\n")[:-1]]
+    assert rc == 0 and len(want) >= 1
+    rc, out, err = _run(args + ["--inputs=" + ",".join(files)], b"")
+    assert rc == 0, err
+    per_ch = {0: [], 1: [], 2: []}
+    for l in out.strip().split("\n")[:-1]:
+        m = re.match(r"^\*\*\*  ch=(\d+); (.*)$", l)
+        assert m, l
+        per_ch[int(m.group(1))].append("***  " + re.sub(r"date=\d{14}", "date=X", m.group(2)))
+    assert per_ch[0] == want and per_ch[2] == want and per_ch[1] == []
+
+
 def test_cli_s1_stream_light_config(orc):
     """BASELINE configs[0]/[1] stand-in (demo/0001.wav is absent): the S1 functional stream at the README's
     'optimal scan' options, HIP program vs the oracle-driven CPU decoder, line for line."""
