@@ -122,6 +122,7 @@ struct Stream
     bool fifo = false;            // a FIFO reads 0 bytes while no writer has connected yet: that is not its end
     bool connected = false;       // first byte seen
     bool eof = false;
+    bool readable = true;         // worth a read(): set by poll(), cleared when a read would block (a regular file always is)
     bool first = true;            // next hop is the 5184-sample fill (main.cu:271-283), later ones 2592 (:284-294)
     size_t skip = 0;              // header bytes still to drop
     std::vector<unsigned char> pending;
@@ -457,6 +458,7 @@ int main(int argc, char* const argv[])
     };
 
     std::vector<pollfd> pfd(nch);
+    std::vector<int> pfd_stream(nch);
     std::vector<unsigned char> chunk(1 << 16);
     std::vector<unsigned char> block;  // --interleaved: one hop of every stream
     bool skip_block = skip_wav;
@@ -509,13 +511,12 @@ int main(int argc, char* const argv[])
         for(int c = 0; c < nch && interleaved == 0; c++)
         {
             Stream& s = st[c];
-            if(s.eof)
-            {
-                if(s.ready) ready++;
-                continue;
-            }
+            if(s.eof) continue;
             open_streams++;
             const size_t need = s.first ? win_bytes : half;
+            // only streams poll() reported (or never asked about) are read: at thousands of streams the read() calls that would
+            // just say EAGAIN were most of the ingest time.  A FIFO still waiting for its writer is probed every round.
+            if(!s.readable && !(s.fifo && !s.connected)) continue;
             while(!s.ready)
             {
                 const size_t room = s.skip ? (s.skip < chunk.size() ? s.skip : chunk.size()) : need - s.pending.size();
@@ -547,10 +548,12 @@ int main(int argc, char* const argv[])
                     s.eof = true;
                     open_streams--;
                 }
+                else if(errno != EINTR) s.readable = false;  // drained: wait for poll() to say otherwise
                 break;
             }
-            if(s.ready) ready++;
         }
+        for(int c = 0; c < nch && interleaved == 0; c++)
+            if(st[c].ready) ready++;
         ingest_busy_ms += ms_between(d0, Clock::now());
         if(open_streams == 0 && ready == 0) break;
 
@@ -568,8 +571,14 @@ int main(int argc, char* const argv[])
             // sleep until more data arrives; a FIFO nobody writes to yet polls as hung-up at once, so it is left out of the set
             int n = 0;
             for(int c = 0; c < nch; c++)
-                if(!st[c].eof && !st[c].ready && (st[c].connected || !st[c].fifo)) pfd[n++] = {st[c].fd, POLLIN, 0};
-            poll(pfd.data(), static_cast<nfds_t>(n), ready > 0 ? 5 : (n > 0 ? 50 : 10));
+                if(!st[c].eof && !st[c].ready && !st[c].readable && (st[c].connected || !st[c].fifo))
+                {
+                    pfd[n] = {st[c].fd, POLLIN, 0};
+                    pfd_stream[n++] = c;
+                }
+            if(poll(pfd.data(), static_cast<nfds_t>(n), ready > 0 ? 5 : (n > 0 ? 50 : 10)) > 0)
+                for(int k = 0; k < n; k++)
+                    if(pfd[k].revents) st[pfd_stream[k]].readable = true;  // data, hang-up or error: the next read() tells which
             continue;
         }
 
