@@ -38,6 +38,18 @@ def test_gpus2_self_launch_reports_two_ranks():
     assert "roofline" in out and out["roofline"]["mode"]
 
 
+def test_gpus8_self_launch_on_gloo():
+    """The shape of the driver's 8-GPU run (BASELINE configs[3]: channels sharded over eight ranks, one gather per step), rehearsed
+    with eight gloo ranks on the CPU and the stub backend."""
+    p = _run(["--gpus", "8"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "channel-shard x8"
+    g = out["gather"]
+    assert g["peak_records_per_rank"] == [5, 6, 7, 8, 8, 8, 8, 8] and g["records_last_step"] == 58      # min(channels, 5 + rank) records per rank
+    assert len(out["rank_ms_per_step"]["per_rank"]) == 8
+
+
 def test_gpus1_through_launcher_matches_contract():
     p = _run(["--gpus", "1", "--launcher"])
     assert p.returncode == 0, p.stderr[-2000:]
