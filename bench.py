@@ -156,6 +156,20 @@ class HipBackend:
     def results(self):
         return self.dec.results()
 
+    def marker(self):
+        """Timing event on the decode stream (torch's current stream: the handle runs on it, set_stream above)."""
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    @staticmethod
+    def ms_between(a, b):
+        return a.elapsed_time(b)
+
+    def clock_probe(self):
+        """Shader clock (MHz) read by a one-wave kernel BESIDE the queued steps (msk144_clock_probe)."""
+        return self.dec.clock_probe(1000)
+
     def close(self):
         self.dec.close()
 
@@ -227,6 +241,42 @@ def roofline_valu(valu, lds, dom):
     return out
 
 
+def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 4, window: int = 50):
+    """The same step, n_steps more times, never letting the GPU run dry: the host keeps `depth` steps queued and waits for step
+    i - depth before it enqueues step i.  Every step ends with a timing marker on the decode stream; the step time of a stretch is
+    the marker-to-marker time over it.  The shader clock is probed beside the running steps at the start, the middle and the end
+    (HipBackend.clock_probe: a one-wave kernel on a side stream, s_memtime / s_memrealtime).  Every rank runs the same n_steps
+    (the gather of a distributed run is a collective); rank 0 reports."""
+    window = max(2, min(window, n_steps // 3))
+    marks, clocks = [], {}
+    probe_at = {depth + 2: "first", n_steps // 2: "mid", n_steps - 3: "last"} if hasattr(be, "clock_probe") else {}
+    fence()
+    t0 = time.perf_counter()
+    marks.append(be.marker())
+    for i in range(n_steps):
+        if i >= depth:
+            marks[i - depth + 1].synchronize()
+        step(first_index + i)
+        marks.append(be.marker())
+        if i in probe_at:
+            clocks[probe_at[i]] = round(be.clock_probe(), 1)
+    fence()
+    wall = time.perf_counter() - t0
+
+    def stretch(a, b):
+        return be.ms_between(marks[a], marks[b]) / (b - a)
+
+    mid = (n_steps - window) // 2
+    ms = {"first%d" % window: stretch(0, window), "mid%d" % window: stretch(mid, mid + window), "last%d" % window: stretch(n_steps - window, n_steps),
+          "all": stretch(0, n_steps)}
+    first, last = ms["first%d" % window], ms["last%d" % window]
+    return {"steps": n_steps, "seconds": wall, "queue_depth": depth, "ms_per_step": {k: round(v, 4) for k, v in ms.items()},
+            "drift_last_vs_first": (last / first - 1.0) if first > 0 else None, "wall_ms_per_step": wall / n_steps * 1e3,
+            "clock_mhz": clocks or None,
+            "note": "same step and inputs as the timed region, run on after it; markers = HIP events on the decode stream; clock_mhz = shader clock read by a "
+                    "one-wave probe beside the running steps (s_memtime / s_memrealtime x 100 MHz); `value` is NOT taken from this leg"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +285,9 @@ def parse_args(argv=None):
     ap.add_argument("--channels", type=int, default=CHANNELS_PER_GPU, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--llr-block", type=int, default=0, help="channels per softbits->index->LDPC block (0 = library default; = channels: retain every LLR row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=10.0,
+                    help="after the K timed steps, keep running the same step for about this long (untimed inputs unchanged) and report the step time of its "
+                         "first / middle / last 50 steps and the shader clock: `value` stays the K-step figure (0 = skip)")
     ap.add_argument("--launcher", action="store_true", help="go through the N-rank launcher even for --gpus 1 (exercises the RCCL gather path)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend-module", default=None, help="TEST HOOK: module providing Backend (e.g. tests/stub_backend.py on gloo); the line is then labelled as such")
@@ -251,10 +304,24 @@ def launch_ranks(args, argv) -> int:
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cpu_file = None
+    if not args.no_cpu_baseline and not args.backend_module:
+        # The CPU baseline is timed HERE, before any rank exists: nothing else of the job runs on the host cores meanwhile (timed on
+        # rank 0 it shared them with the other ranks' start-up).  numpy + the oracle library only - still no GPU API in this process.
+        import tempfile
+        cpu = cpu_baseline(make_inputs(0, args.channels)[0])
+        cpu["sample"] += "; timed in the launcher parent before the ranks were started"
+        fd, cpu_file = tempfile.mkstemp(prefix="msk144_cpu_baseline_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(cpu, f)
+        env["MSK144_BENCH_CPU_BASELINE_FILE"] = cpu_file
+        _INPUTS.clear()
     passed = [a for a in argv if a != "--launcher"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + passed + ["--worker"]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    if cpu_file:
+        os.unlink(cpu_file)
     line = None
     for ln in proc.stdout.splitlines():
         t = ln.strip()
@@ -295,10 +362,15 @@ def run_worker(args) -> int:
     # The CPU baseline runs FIRST, on rank 0, before anything touches the GPU: the GPU phase is then the tail of the process
     # (a sampler of GPU activity catches it), and the other ranks of a distributed run simply wait for rank 0 at the rendezvous.
     cpu = None
+    handed = os.environ.get("MSK144_BENCH_CPU_BASELINE_FILE")
     if rank == 0 and not args.no_cpu_baseline and Backend is HipBackend:
-        cpu = cpu_baseline(make_inputs(0, channels)[0])
-        if distributed and world > 1:
-            cpu["sample"] += f"; timed while the other {world - 1} rank(s) of the job were starting up on the same host"
+        if handed and os.path.exists(handed):
+            cpu = json.load(open(handed))          # bench.py --gpus N: timed by the launcher parent before the ranks existed
+        else:
+            cpu = cpu_baseline(make_inputs(0, channels)[0])
+            _INPUTS.clear()                        # the GPU phase stages its own copy; do not keep a second one alive
+            if distributed and world > 1:
+                cpu["sample"] += f"; timed while the other {world - 1} rank(s) of the job were starting up (torch import, rendezvous wait) on the same host"
 
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -353,6 +425,13 @@ def run_worker(args) -> int:
 
     stage = be.stage_times()
     last = be.results()
+
+    sustained = None
+    if args.sustain_seconds > 0 and hasattr(be, "marker"):
+        n_sus = int(min(100000, max(150, -(-args.sustain_seconds * args.steps // max(elapsed, 1e-9)))))   # same count on every rank: `elapsed` is the max over ranks
+        sustained = sustained_leg(be, step, fence, n_sus, args.warmup + args.steps)
+        st2 = be.stage_times()      # averages over the timed region AND the sustained leg (profiling stayed on)
+        sustained["stage_ms_incl_timed_region"] = {n: round(st2[n][0], 4) for n in be.T_NAMES}
     # Payloads that are not the channel's transmitted message.  The reference algorithm accepts on CRC-13
     # + < 18 hard errors, so at 1.6e7 BP attempts per step a few false positives are expected; they are
     # the oracle's too (tests/test_gpu_full.py), not decoder errors.
@@ -449,6 +528,8 @@ def run_worker(args) -> int:
             out["gather"] = {"records_last_step": gathered_records, "capacity_per_rank": gather.cap, "bytes_per_rank": int(gather.send.numel()),
                              "peak_records_per_rank": [int(x) for x in gather.max_total.cpu().numpy()], "backend": Backend.dist_backend,
                              "ms_per_step": gather.mean_ms(), "ms_note": "copy into the send buffer + gather, timed on rank 0 around RecordGather.step"}
+        if sustained is not None:
+            out["sustained"] = sustained
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

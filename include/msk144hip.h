@@ -22,6 +22,10 @@
  *   msk144_fetch_wait        D2H of what the host loop consumes)  main.cu:261-422, 474-525
  *   msk144_dump_candidates   the raw ResultItem array (parity/debug)     result_keeper.cuh:17-32,123-130
  *   msk144_destroy           ~MSK144SearchContext / deinit        msk_context.cuh:81-120
+ *   msk144_device_count      cudaGetDeviceCount behind cudaSetDeviceFlags (the reference drives device 0 only; the multi-device
+ *                            stream program asks how many it may split its streams over)   main.cu:115
+ *   msk144_clock_probe       gpu_timer.h's role for the one figure HIP events cannot give: the shader clock a running batch
+ *                            actually gets (s_memtime / s_memrealtime), read beside it on a side stream
  *
  * One handle = one device + one HIP stream + `channels` independent input streams decoded per call
  * (the reference decodes one).  Plain pointers and sizes only; no exceptions cross the boundary:
@@ -145,6 +149,10 @@ typedef struct msk144_handle msk144_handle;
 /* defaults exactly as main.cu:122-133 (NOT the help text) */
 void msk144_default_params(msk144_params* p);
 
+/* HIP devices visible to this process (0 and MSK144_EHIP when there is none): what msk144_params.device may range over.  The
+ * reference binds the process to one device (main.cu:115); msk144hipdecoder --devices=... creates one handle per listed ordinal. */
+int msk144_device_count(int32_t* n);
+
 int msk144_create(const msk144_params* params, msk144_handle** out);
 void msk144_destroy(msk144_handle* h);
 /* h may be NULL: error text of the last failed msk144_create on this thread */
@@ -238,6 +246,13 @@ int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candi
  * msk144_decode / msk144_submit_* call and averaged over the calls since the last reset; samples[s] = calls measured */
 int msk144_set_profiling(msk144_handle* h, int32_t enable);
 int msk144_stage_times(msk144_handle* h, float* avg_ms /*[MSK144_T_COUNT]*/, int32_t* samples /*[MSK144_T_COUNT] or NULL*/, int32_t reset);
+
+/* Shader clock the handle's device runs at right now, in MHz: a one-wave kernel on a side stream of the handle spins for spin_us
+ * microseconds of the constant 100 MHz counter (s_memrealtime) and divides the shader cycles that passed (s_memtime) by it.  It runs
+ * BESIDE whatever the handle's stream is executing (one wave, no LDS), so calling it right after msk144_decode reads the clock the
+ * decode kernels get - the number a sustained-throughput claim needs next to its step time (DVFS: a chip that has idled for a hop
+ * period starts its next batch at a lower clock).  Blocks the caller for about spin_us.  spin_us 1..100000. */
+int msk144_clock_probe(msk144_handle* h, int32_t spin_us, float* shader_mhz);
 
 #ifdef __cplusplus
 }

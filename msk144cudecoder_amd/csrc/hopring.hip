@@ -40,7 +40,34 @@ __global__ __launch_bounds__(kRingThreads) void hop_ring_kernel(uint32_t* __rest
     }
 }
 
+// Shader clock probe (msk144_clock_probe): spins on the constant 100 MHz counter and reports how many shader cycles went by.  The
+// loop is bounded twice - by the tick target and by an iteration cap (each round sleeps 8 x 64 cycles: 2^21 rounds < 0.5 s at any
+// clock) - so the wave always ends.
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint64_t* __restrict__ out, uint32_t ticks)
+{
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint64_t r1 = r0;
+    for(int i = 0; i < (1 << 21) && r1 - r0 < ticks; i++)
+    {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if(threadIdx.x == 0)
+    {
+        out[0] = t1 - t0;
+        out[1] = r1 - r0;
+    }
+}
+
 }  // namespace
+
+void launch_clock_probe(uint64_t* out, uint32_t ticks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, out, ticks);
+}
 
 void launch_hop_ring(void* ring, const void* hops, const void* first_halves, const int32_t* streams, const uint8_t* is_first, void* windows, int n, hipStream_t stream)
 {

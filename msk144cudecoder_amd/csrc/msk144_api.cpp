@@ -89,6 +89,9 @@ struct msk144_handle
     int32_t* d_streams = nullptr;
     uint8_t* d_isfirst = nullptr;
     bool ring_ready = false;
+    // msk144_clock_probe: its own stream, so that the probe wave runs beside the decode kernels
+    hipStream_t probe_stream = nullptr;
+    uint64_t* d_probe = nullptr;
 
     std::string error;
 };
@@ -333,6 +336,19 @@ const char* msk144_last_error(const msk144_handle* h)
     return h ? h->error.c_str() : g_create_error.c_str();
 }
 
+int msk144_device_count(int32_t* n)
+{
+    if(!n) return fail(nullptr, MSK144_EINVAL, "null argument");
+    int ndev = 0;
+    if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        *n = 0;
+        return fail(nullptr, MSK144_EHIP, "no HIP device available (libmsk144hip has no CPU fallback)");
+    }
+    *n = ndev;
+    return MSK144_OK;
+}
+
 int msk144_create(const msk144_params* params, msk144_handle** out)
 {
     if(!params || !out) return fail(nullptr, MSK144_EINVAL, "null argument");
@@ -486,6 +502,8 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
 void msk144_destroy(msk144_handle* h)
 {
     if(!h) return;
+    (void)hipSetDevice(h->params.device);
+    if(h->probe_stream) (void)hipStreamSynchronize(h->probe_stream);
     if(h->stream) (void)hipStreamSynchronize(h->stream);
     for(void* p : h->allocs) (void)hipFree(p);
     for(auto& sl : h->slots)
@@ -501,6 +519,7 @@ void msk144_destroy(msk144_handle* h)
         if(sl.done) (void)hipEventDestroy(sl.done);
     }
     if(h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if(h->probe_stream) (void)hipStreamDestroy(h->probe_stream);
     for(const auto& sp : h->spans_pending)
     {
         (void)hipEventDestroy(sp.e0);
@@ -663,6 +682,7 @@ int msk144_decode(msk144_handle* h)
 int msk144_synchronize(msk144_handle* h)
 {
     if(!h) return MSK144_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->params.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     harvest_times(h);
     return MSK144_OK;
@@ -934,6 +954,27 @@ int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candi
     HIP_TRY(h, hipMemcpy(st.llr + off * kCodeBits, llr.data(), K * kCodeBits * 4, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemsetAsync(st.dec_flag + off, 0, K, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MSK144_OK;
+}
+
+int msk144_clock_probe(msk144_handle* h, int32_t spin_us, float* shader_mhz)
+{
+    if(!h || !shader_mhz) return fail(h, MSK144_EINVAL, "null argument");
+    if(spin_us < 1 || spin_us > 100000) return fail(h, MSK144_EINVAL, "spin_us must be 1..100000");
+    HIP_TRY(h, hipSetDevice(h->params.device));
+    if(!h->probe_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->probe_stream, hipStreamNonBlocking));
+    if(!h->d_probe)
+    {
+        int rc = dev_alloc(h, &h->d_probe, 2);
+        if(rc != MSK144_OK) return rc;
+    }
+    launch_clock_probe(h->d_probe, static_cast<uint32_t>(spin_us) * 100u, h->probe_stream);
+    HIP_TRY(h, hipGetLastError());
+    uint64_t v[2] = {0, 0};
+    HIP_TRY(h, hipMemcpyAsync(v, h->d_probe, sizeof(v), hipMemcpyDeviceToHost, h->probe_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->probe_stream));
+    if(v[1] == 0) return fail(h, MSK144_EHIP, "clock probe: the 100 MHz counter did not advance");
+    *shader_mhz = static_cast<float>(static_cast<double>(v[0]) / static_cast<double>(v[1]) * 100.0);
     return MSK144_OK;
 }
 

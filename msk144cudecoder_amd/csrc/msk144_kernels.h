@@ -70,6 +70,9 @@ void launch_frontend_iq(const DeviceStore& st, const int8_t* d_in, hipStream_t s
 // first_halves[j] + hops[j] when is_first[j]); windows[j] = the stream's new window.  Halves and windows in raw input bytes.
 void launch_hop_ring(void* ring, const void* hops, const void* first_halves, const int32_t* streams, const uint8_t* is_first, void* windows, int n, hipStream_t stream);
 
+// one wave that spins for `ticks` of the 100 MHz counter; out[0] = shader cycles elapsed, out[1] = 100 MHz ticks elapsed (hopring.hip)
+void launch_clock_probe(uint64_t* out, uint32_t ticks, hipStream_t stream);
+
 // hot kernels
 void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t stream);
 void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t stream);

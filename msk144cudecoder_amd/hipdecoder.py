@@ -28,6 +28,7 @@ ABI_SYMBOLS = (
     "msk144_result_count", "msk144_results_device", "msk144_set_channel_base", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
     "msk144_input_slot", "msk144_submit_slot", "msk144_submit_slot_n", "msk144_fetch_async", "msk144_fetch_wait", "msk144_hop_slot", "msk144_push_hops",
+    "msk144_device_count", "msk144_clock_probe",
 )
 
 
@@ -108,6 +109,8 @@ def load_library(path: Optional[str] = None):
     L.msk144_push_hops.argtypes = [vp, i32, i32]
     L.msk144_fetch_async.argtypes = [vp, i32]
     L.msk144_fetch_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp)]
+    L.msk144_device_count.argtypes = [C.POINTER(i32)]
+    L.msk144_clock_probe.argtypes = [vp, i32, C.POINTER(C.c_float)]
     if path is None:
         _lib = L
     return L
@@ -294,6 +297,22 @@ class HipDecoder:
         cnt = np.zeros(len(T_NAMES), dtype=np.int32)
         self._chk(self.L.msk144_stage_times(self.h, _ptr(ms), _ptr(cnt), 1 if reset else 0))
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(T_NAMES)}
+
+    def clock_probe(self, spin_us: int = 1000) -> float:
+        """Shader clock in MHz read by a one-wave kernel beside whatever the decode stream is running (blocks ~spin_us)."""
+        mhz = C.c_float(0.0)
+        self._chk(self.L.msk144_clock_probe(self.h, int(spin_us), C.byref(mhz)))
+        return float(mhz.value)
+
+
+def device_count() -> int:
+    """HIP devices the library sees (raises without one: there is no CPU fallback)."""
+    n = C.c_int32(0)
+    L = load_library()
+    rc = L.msk144_device_count(C.byref(n))
+    if rc != 0:
+        raise Msk144Error(rc, (L.msk144_last_error(None) or b"").decode())
+    return int(n.value)
 
 
 def unpack_message(msg10: np.ndarray) -> np.ndarray:

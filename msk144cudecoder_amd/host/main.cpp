@@ -3,30 +3,23 @@
 // (main.cu:55-426), with the GPU work behind libmsk144hip.so.  Beyond the reference: several raw
 // streams (files or FIFOs) decoded as ONE GPU batch per hop, read without blocking so that a stalled stream never holds
 // the others back, with per-stream hop-deadline accounting (the reference's 210 ms watchdog, per batch and per stream).  The
-// multi-stream loop is pipelined over the library's two pinned staging slots: this thread reads the streams and submits hop n+1
-// while the GPU decodes hop n and a second thread turns the records of hop n-1 into text.
-#include "window_decoder.h"
+// multi-stream loop is pipelined over the library's two pinned staging slots (stream_loop.h): an ingest thread reads the streams and
+// submits hop n+1 while the GPU decodes hop n and a second thread turns the records of hop n-1 into text.  --devices=0,1,... runs
+// one such loop per GPU, each on its contiguous share of the streams (the reference binds to one device, main.cu:115).
+#include "stream_loop.h"
 
-#include <fcntl.h>
 #include <getopt.h>
-#include <poll.h>
 #include <sys/resource.h>
-#include <sys/stat.h>
-#include <unistd.h>
 
 #include <algorithm>
-#include <cerrno>
 #include <chrono>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
 #include <fstream>
 #include <iostream>
-#include <mutex>
+#include <memory>
 #include <string>
-#include <thread>
 #include <vector>
 
 using namespace msk144host;
@@ -62,6 +55,8 @@ void show_help(const char* prog)
     std::cout << "                   --strict-decode             Accepted for compatibility (this is the default now)." << std::endl;
     std::cout << "                   --print-bits                Append the 77-bit payload to each output line." << std::endl;
     std::cout << "                   --device=N                  HIP device ordinal. Default=0." << std::endl;
+    std::cout << "                   --devices=N1,N2,...|all     With --inputs/--interleaved: split the streams contiguously over these devices; each device gets its own ingest and post-processing threads, ch=<index> stays the global stream number. An ordinal may repeat (two independent loops on one GPU)." << std::endl;
+    std::cout << "                   --max-results=N             Capacity of the per-hop decode list of a device (default 256 per stream + 131072). A hop that exceeds it is cut and reported; decoding goes on." << std::endl;
     std::cout << "                   --timing                    With --inputs: per-hop host and device time split (ingest, H2D, GPU, D2H, post-processing) on stderr at the end." << std::endl;
     // clang-format on
 }
@@ -96,71 +91,11 @@ void warn_if_late(long long ms)
     }
 }
 
-void print_lines(int nch, const std::vector<std::vector<FilteredResult>>& lines)
+// one share of the input streams: the loop of `device` decodes global streams [first, first + count)
+struct Share
 {
-    for(int c = 0; c < nch; c++)
-    {
-        for(const FilteredResult& l : lines[c])
-        {
-            if(nch == 1)
-            {
-                std::cout << l.format_line() << std::endl;
-            }
-            else
-            {
-                const std::string line = l.format_line();  // "***  snr=..." -> "***  ch=<c>; snr=..."
-                std::cout << line.substr(0, 5) << "ch=" << c << "; " << line.substr(5) << std::endl;
-            }
-        }
-    }
-}
-
-// One --inputs stream: a non-blocking descriptor and the bytes read so far towards its next hop.
-struct Stream
-{
-    int fd = -1;
-    bool fifo = false;            // a FIFO reads 0 bytes while no writer has connected yet: that is not its end
-    bool connected = false;       // first byte seen
-    bool eof = false;
-    bool readable = true;         // worth a read(): set by poll(), cleared when a read would block (a regular file always is)
-    bool first = true;            // next hop is the 5184-sample fill (main.cu:271-283), later ones 2592 (:284-294)
-    size_t skip = 0;              // header bytes still to drop
-    std::vector<unsigned char> pending;
-    bool ready = false;           // a complete hop sits in `pending`
-    Clock::time_point ready_at;
-    // deadline accounting (owned by the post-processing thread)
-    long hops = 0, late = 0;
-    long long worst_ms = 0;
+    int device = 0, first = 0, count = 0;
 };
-
-// One submitted hop of every ready stream, handed from the ingest thread to the post-processing thread.
-struct Batch
-{
-    int slot = 0;
-    int n = 0;                                 // streams that have a hop in this batch
-    std::vector<int> streams;                  // which ones, ascending
-    std::vector<Clock::time_point> ready_at;  // when each of them had its hop complete
-    Clock::time_point go;                      // batch released by the policy
-    double assemble_ms = 0.0, submit_ms = 0.0;
-};
-
-struct Accumulator
-{
-    double sum = 0.0, worst = 0.0;
-    long n = 0;
-    void add(double v)
-    {
-        sum += v;
-        worst = std::max(worst, v);
-        n++;
-    }
-    double mean() const { return n ? sum / n : 0.0; }
-};
-
-double ms_between(Clock::time_point a, Clock::time_point b)
-{
-    return std::chrono::duration<double, std::milli>(b - a).count();
-}
 
 }  // namespace
 
@@ -174,6 +109,7 @@ int main(int argc, char* const argv[])
     int interleaved = 0;
     bool timing = false;
     std::vector<std::string> input_paths;
+    std::vector<std::string> device_list;
 
     static struct option long_options[] = {{"help", no_argument, 0, 0},
                                            {"center-frequency", required_argument, 0, 0},
@@ -194,6 +130,8 @@ int main(int argc, char* const argv[])
                                            {"timing", no_argument, 0, 0},
                                            {"connect-timeout-ms", required_argument, 0, 0},
                                            {"interleaved", required_argument, 0, 0},
+                                           {"devices", required_argument, 0, 0},
+                                           {"max-results", required_argument, 0, 0},
                                            {0, 0, 0, 0}};
     while(true)
     {
@@ -233,6 +171,8 @@ int main(int argc, char* const argv[])
         case 16: timing = true; break;
         case 17: connect_timeout_ms = atoi(optarg); break;
         case 18: interleaved = atoi(optarg); break;
+        case 19: split_list(optarg, device_list); break;
+        case 20: opt.max_results = atoi(optarg); break;
         default: show_help(argv[0]); return 0;
         }
     }
@@ -262,7 +202,6 @@ int main(int argc, char* const argv[])
     }
     const bool batched = interleaved > 0 || !input_paths.empty();
     const int nch = interleaved > 0 ? interleaved : (input_paths.empty() ? 1 : static_cast<int>(input_paths.size()));
-    opt.channels = nch;
     opt.profile = timing && batched;
     {
         // one descriptor per stream plus what the runtime opens: lift the soft limit when the hard limit allows
@@ -275,7 +214,46 @@ int main(int argc, char* const argv[])
         }
     }
 
-    WindowDecoder dec(opt);
+    // which device decodes which streams: contiguous shares, sizes differing by at most one
+    std::vector<int> devices;
+    if(device_list.size() == 1 && device_list[0] == "all")
+    {
+        int32_t n = 0;
+        if(msk144_device_count(&n) != MSK144_OK)
+        {
+            std::cerr << "msk144hip: " << msk144_last_error(nullptr) << std::endl;
+            return 2;
+        }
+        for(int d = 0; d < n; d++) devices.push_back(d);
+    }
+    else
+        for(const std::string& d : device_list) devices.push_back(atoi(d.c_str()));
+    if(devices.empty()) devices.push_back(opt.device);
+    if(devices.size() > 1 && !batched)
+    {
+        std::cerr << "--devices splits the streams of --inputs / --inputs-file / --interleaved; a single stdin stream runs on one device (--device=N)" << std::endl;
+        return 2;
+    }
+    std::vector<Share> shares(std::min<size_t>(devices.size(), static_cast<size_t>(nch)));  // a device without a stream gets no loop
+    for(size_t i = 0; i < shares.size(); i++)
+    {
+        shares[i].device = devices[i];
+        split_streams(nch, static_cast<int>(shares.size()), static_cast<int>(i), shares[i].first, shares[i].count);
+    }
+    opt.device = shares[0].device;
+    opt.channels = shares[0].count;
+
+    LinePrinter printer;
+    LoopOptions lo;
+    lo.hop_timeout_ms = hop_timeout_ms;
+    lo.connect_timeout_ms = connect_timeout_ms;
+    lo.skip_wav = skip_wav;
+    lo.tag_channels = nch > 1;
+    std::unique_ptr<WindowDecoder> single;
+    std::unique_ptr<DeviceLoop> first_loop;
+    if(batched) first_loop = std::make_unique<DeviceLoop>(opt, 0, lo, printer);
+    else single = std::make_unique<WindowDecoder>(opt);
+    WindowDecoder& dec = batched ? first_loop->decoder() : *single;
     if(!dec.ok())
     {
         std::cerr << "msk144hip: " << dec.error() << std::endl;
@@ -304,12 +282,13 @@ int main(int argc, char* const argv[])
     std::cerr << "msk144hipdecoder: " << F << " frequency hypotheses x " << D << " patterns x 8 = " << F * D * 8 << " candidates per window; HIP workgroups per window: scan "
               << F << " x 512, softbits " << F << " x 512, LDPC one wave per gated candidate" << std::endl;
     if(batched) std::cerr << "msk144hipdecoder: " << nch << " input streams per GPU batch" << (interleaved > 0 ? " (interleaved on stdin)" : "") << ", hop timeout " << hop_timeout_ms << " ms" << std::endl;
+    if(shares.size() > 1)
+        for(const Share& sh : shares) std::cerr << "msk144hipdecoder: device " << sh.device << " decodes streams " << sh.first << ".." << sh.first + sh.count - 1 << std::endl;
 
     const size_t sample_bytes = (opt.read_mode == 1) ? sizeof(int16_t) : 2 * sizeof(int8_t);
     const size_t win_bytes = MSK144_WINDOW_SAMPLES * sample_bytes;
     const size_t half = win_bytes / 2;
     const size_t unit = (opt.read_mode == 1) ? sizeof(int16_t) : sizeof(int8_t);  // the reference counts items of this size
-    std::vector<std::vector<FilteredResult>> lines;
 
     if(!batched)
     {
@@ -321,7 +300,7 @@ int main(int argc, char* const argv[])
         }
         std::vector<unsigned char> ring(win_bytes, 0);
         bool first = true;
-        const std::vector<bool> active(1, true);
+        std::vector<FilteredResult> lines;
         while(true)
         {
             unsigned char* w = ring.data();
@@ -344,328 +323,122 @@ int main(int argc, char* const argv[])
                 break;
             }
             const auto t0 = Clock::now();
-            if(!dec.process(ring.data(), active, lines))
+            if(!dec.process(ring.data(), lines))
             {
                 std::cerr << "msk144hip: " << dec.error() << std::endl;
                 return 2;
             }
+            if(dec.last_hop_overflowed()) std::cerr << "msk144hipdecoder: the window held more decodes than the result list (raise --max-results): the list was cut, decoding goes on" << std::endl;
             warn_if_late(std::chrono::duration_cast<std::chrono::milliseconds>(Clock::now() - t0).count());
-            print_lines(1, lines);
+            for(const FilteredResult& l : lines) std::cout << l.format_line() << std::endl;
         }
         std::cout << "Done" << std::endl;
         return 0;
     }
 
-    // ---- several streams, one GPU batch per hop, non-blocking ingest, pipelined over two staging slots ----
-    std::vector<Stream> st(nch);
-    for(int c = 0; c < nch && interleaved > 0; c++)
+    // ---- several streams: one DeviceLoop per listed device (stream_loop.h), each with its contiguous share of the streams ----
+    std::vector<std::unique_ptr<DeviceLoop>> loops;
+    loops.push_back(std::move(first_loop));
+    for(size_t i = 1; i < shares.size(); i++)
     {
-        st[c].pending.reserve(win_bytes);
-    }
-    for(int c = 0; c < nch && interleaved == 0; c++)
-    {
-        // O_NONBLOCK: opening a FIFO whose writer has not arrived yet returns at once, and read() never parks the batch
-        st[c].fd = open(input_paths[c].c_str(), O_RDONLY | O_NONBLOCK);
-        if(st[c].fd < 0)
+        DecoderOptions o = opt;
+        o.device = shares[i].device;
+        o.channels = shares[i].count;
+        loops.push_back(std::make_unique<DeviceLoop>(o, shares[i].first, lo, printer));
+        if(!loops.back()->ok())
         {
-            std::cerr << "Cannot open input " << input_paths[c] << ": " << strerror(errno) << std::endl;
-            return 2;
-        }
-        st[c].skip = skip_wav ? 44 : 0;
-        st[c].pending.reserve(win_bytes);
-        struct stat sb{};
-        st[c].fifo = fstat(st[c].fd, &sb) == 0 && S_ISFIFO(sb.st_mode);
-    }
-    const auto opened_at = Clock::now();
-    WindowDecoder::HopStage stage[WindowDecoder::kSlots];
-    for(int k = 0; k < WindowDecoder::kSlots; k++)
-    {
-        if(!dec.hop_stage(k, stage[k]))  // pinned, owned by the library handle; the stream windows themselves live on the device
-        {
-            std::cerr << "msk144hip: " << dec.error() << std::endl;
+            std::cerr << "msk144hip: device " << o.device << ": " << loops.back()->error() << std::endl;
             return 2;
         }
     }
+    for(size_t i = 0; i < loops.size(); i++)
+    {
+        if(interleaved > 0) loops[i]->use_feed();
+        else if(!loops[i]->open_inputs(std::vector<std::string>(input_paths.begin() + shares[i].first, input_paths.begin() + shares[i].first + shares[i].count)))
+        {
+            std::cerr << loops[i]->error() << std::endl;
+            return 2;
+        }
+    }
+    const auto run_since = Clock::now();
+    for(auto& l : loops) l->start();
 
-    // hand-over between this (ingest + submit) thread and the post-processing thread
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<Batch> in_flight;
-    std::deque<int> free_slots;
-    for(int k = 0; k < WindowDecoder::kSlots; k++) free_slots.push_back(k);
-    bool no_more = false, failed = false;
-    Accumulator t_assemble, t_submit, t_wait, t_post, t_print, t_latency, t_records;
-    long batches = 0;
-
-    std::thread post([&]() {
-        std::vector<std::vector<FilteredResult>> out;
+    if(interleaved > 0)
+    {
+        // one block per hop on stdin: the hop of stream 0, then of stream 1, ... (blocking read, like the reference's fread); every
+        // loop receives the slice of its own streams
+        if(skip_wav)
+        {
+            unsigned char hdr[44];
+            if(fread(hdr, 1, sizeof(hdr), stdin) != sizeof(hdr)) printer.log("Incomplete read error. rc=0");
+        }
+        std::vector<unsigned char> block;
+        bool first_block = true;
         while(true)
         {
-            Batch b;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !in_flight.empty() || no_more; });
-                if(in_flight.empty()) return;
-                b = std::move(in_flight.front());
-                in_flight.pop_front();
-            }
-            HopTiming ht;
-            if(!dec.collect(b.slot, out, &ht))
-            {
-                std::cerr << "msk144hip: " << dec.error() << std::endl;
-                std::lock_guard<std::mutex> lk(mu);
-                failed = true;
-                cv.notify_all();
-                return;
-            }
-            const auto p0 = Clock::now();
-            print_lines(nch, out);
-            const auto p1 = Clock::now();
-            warn_if_late(std::chrono::duration_cast<std::chrono::milliseconds>(p1 - b.go).count());
-            // per-stream deadline: from "hop complete" to "lines printed" a stream has one hop period (216 ms) before its next
-            // hop is due; the reference's soft limit of 210 ms (main.cu:398-403) is applied per stream
-            for(size_t j = 0; j < b.streams.size(); j++)
-            {
-                Stream& s = st[b.streams[j]];
-                const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(p1 - b.ready_at[j]).count();
-                s.hops++;
-                if(ms > 210) s.late++;
-                if(ms > s.worst_ms) s.worst_ms = ms;
-            }
-            t_assemble.add(b.assemble_ms);
-            t_submit.add(b.submit_ms);
-            t_wait.add(ht.wait_ms);
-            t_post.add(ht.post_ms);
-            t_print.add(ms_between(p0, p1));
-            t_latency.add(ms_between(b.go, p1));
-            t_records.add(ht.records);
-            batches++;
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                free_slots.push_back(b.slot);
-            }
-            cv.notify_all();
-        }
-    });
-    auto finish = [&](int code) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            no_more = true;
-        }
-        cv.notify_all();
-        post.join();
-        return code;
-    };
-
-    std::vector<pollfd> pfd(nch);
-    std::vector<int> pfd_stream(nch);
-    std::vector<unsigned char> chunk(1 << 16);
-    std::vector<unsigned char> block;  // --interleaved: one hop of every stream
-    bool skip_block = skip_wav;
-    Accumulator t_ingest;
-    auto ingest_since = Clock::now();
-    double ingest_busy_ms = 0.0;
-
-    while(true)
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if(failed) break;
-        }
-        // 1. drain whatever every open stream has, up to one hop each
-        const auto d0 = Clock::now();
-        int open_streams = 0, ready = 0;
-        if(interleaved > 0 && !st[0].eof)
-        {
-            // one block per hop on stdin: the hop of stream 0, then of stream 1, ... (blocking read, like the reference's fread)
-            const size_t need = st[0].first ? win_bytes : half;
+            const size_t need = first_block ? win_bytes : half;
             block.resize(need * nch);
-            if(skip_block)
-            {
-                unsigned char hdr[44];
-                if(fread(hdr, 1, sizeof(hdr), stdin) != sizeof(hdr)) std::cerr << "Incomplete read error. rc=0" << std::endl;
-                skip_block = false;
-            }
             const size_t got = fread(block.data(), 1, block.size(), stdin);
             if(got != block.size())
             {
-                std::cerr << "Incomplete read error. rc=" << got / unit << std::endl;
-                for(Stream& s : st) s.eof = true;
-            }
-            else
-            {
-                const auto now = Clock::now();
-                for(int c = 0; c < nch; c++)
-                {
-                    st[c].pending.assign(block.begin() + static_cast<long>(need * c), block.begin() + static_cast<long>(need * (c + 1)));
-                    st[c].ready = true;
-                    st[c].ready_at = now;
-                }
-            }
-        }
-        for(int c = 0; c < nch && interleaved > 0; c++)
-        {
-            if(!st[c].eof) open_streams++;
-            if(st[c].ready) ready++;
-        }
-        for(int c = 0; c < nch && interleaved == 0; c++)
-        {
-            Stream& s = st[c];
-            if(s.eof) continue;
-            open_streams++;
-            const size_t need = s.first ? win_bytes : half;
-            // only streams poll() reported (or never asked about) are read: at thousands of streams the read() calls that would
-            // just say EAGAIN were most of the ingest time.  A FIFO still waiting for its writer is probed every round.
-            if(!s.readable && !(s.fifo && !s.connected)) continue;
-            while(!s.ready)
-            {
-                const size_t room = s.skip ? (s.skip < chunk.size() ? s.skip : chunk.size()) : need - s.pending.size();
-                const ssize_t got = read(s.fd, chunk.data(), room < chunk.size() ? room : chunk.size());
-                if(got > 0)
-                {
-                    s.connected = true;
-                    if(s.skip) s.skip -= static_cast<size_t>(got);
-                    else s.pending.insert(s.pending.end(), chunk.begin(), chunk.begin() + got);
-                    if(!s.skip && s.pending.size() == need)
-                    {
-                        s.ready = true;
-                        s.ready_at = Clock::now();
-                    }
-                    continue;
-                }
-                if(got == 0 && s.fifo && !s.connected && ms_between(opened_at, Clock::now()) < connect_timeout_ms)
-                    break;  // no writer on this FIFO yet: read() reports 0 bytes, which only means "nobody there so far"
-                if(got == 0)
-                {
-                    // writer closed: what is left is a short read, exactly the reference's end-of-stream message
-                    std::cerr << "ch=" << c << ": Incomplete read error. rc=" << s.pending.size() / unit << std::endl;
-                    s.eof = true;
-                    open_streams--;
-                }
-                else if(errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)
-                {
-                    std::cerr << "ch=" << c << ": read error: " << strerror(errno) << std::endl;
-                    s.eof = true;
-                    open_streams--;
-                }
-                else if(errno != EINTR) s.readable = false;  // drained: wait for poll() to say otherwise
+                printer.log("Incomplete read error. rc=" + std::to_string(got / unit));
                 break;
             }
+            bool alive = true;
+            for(size_t i = 0; i < loops.size() && alive; i++) alive = loops[i]->feed(block.data() + need * shares[i].first, need);
+            if(!alive) break;
+            first_block = false;
         }
-        for(int c = 0; c < nch && interleaved == 0; c++)
-            if(st[c].ready) ready++;
-        ingest_busy_ms += ms_between(d0, Clock::now());
-        if(open_streams == 0 && ready == 0) break;
-
-        // 2. batch policy: go when every open stream has its hop, or when the oldest ready hop has waited hop_timeout_ms
-        bool go = ready > 0 && ready >= open_streams;
-        if(!go && ready > 0)
-        {
-            Clock::time_point oldest = Clock::now();
-            for(const Stream& s : st)
-                if(s.ready && s.ready_at < oldest) oldest = s.ready_at;
-            go = std::chrono::duration_cast<std::chrono::milliseconds>(Clock::now() - oldest).count() >= hop_timeout_ms;
-        }
-        if(!go)
-        {
-            // sleep until more data arrives; a FIFO nobody writes to yet polls as hung-up at once, so it is left out of the set
-            int n = 0;
-            for(int c = 0; c < nch; c++)
-                if(!st[c].eof && !st[c].ready && !st[c].readable && (st[c].connected || !st[c].fifo))
-                {
-                    pfd[n] = {st[c].fd, POLLIN, 0};
-                    pfd_stream[n++] = c;
-                }
-            if(poll(pfd.data(), static_cast<nfds_t>(n), ready > 0 ? 5 : (n > 0 ? 50 : 10)) > 0)
-                for(int k = 0; k < n; k++)
-                    if(pfd[k].revents) st[pfd_stream[k]].readable = true;  // data, hang-up or error: the next read() tells which
-            continue;
-        }
-
-        // 3. a free staging slot (back-pressure: with both slots in flight the streams wait in their pipes)
-        Batch b;
-        b.go = Clock::now();
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !free_slots.empty() || failed; });
-            if(failed) break;
-            b.slot = free_slots.front();
-            free_slots.pop_front();
-        }
-        // 4. hand the new samples of every stream that has a hop to the library, packed back to back in the pinned slot: 2592 per
-        // stream (all 5184 of a stream's first hop).  The 50 %-overlap window of each stream (main.cu:284-288) lives on the device
-        // (msk144_push_hops); streams without a hop sit this batch out and cost nothing on the GPU
-        const auto a0 = Clock::now();
-        WindowDecoder::HopStage& hs = stage[b.slot];
-        for(int c = 0; c < nch; c++)
-        {
-            Stream& s = st[c];
-            if(!s.ready) continue;
-            const size_t j = b.streams.size();
-            if(s.first)
-            {
-                memcpy(hs.first_halves + half * j, s.pending.data(), half);
-                memcpy(hs.hops + half * j, s.pending.data() + half, half);
-            }
-            else memcpy(hs.hops + half * j, s.pending.data(), half);
-            hs.streams[j] = c;
-            hs.is_first[j] = s.first ? 1 : 0;
-            b.streams.push_back(c);
-            b.ready_at.push_back(s.ready_at);
-            s.first = false;
-            s.pending.clear();
-            s.ready = false;
-        }
-        b.n = static_cast<int>(b.streams.size());
-        const auto a1 = Clock::now();
-        if(!dec.submit_hops(b.slot, b.n))
-        {
-            std::cerr << "msk144hip: " << dec.error() << std::endl;
-            return finish(2);
-        }
-        b.assemble_ms = ms_between(a0, a1);
-        b.submit_ms = ms_between(a1, Clock::now());
-        t_ingest.add(ingest_busy_ms);
-        ingest_busy_ms = 0.0;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            in_flight.push_back(std::move(b));
-        }
-        cv.notify_all();
+        for(auto& l : loops) l->feed_end();
     }
-    finish(0);
-    if(failed) return 2;
 
-    long total_hops = 0, total_late = 0;
+    int rc = 0;
+    for(auto& l : loops) rc = std::max(rc, l->join());
+    if(rc != 0) return rc;
+
+    long total_hops = 0, total_late = 0, batches = 0, overflowed = 0;
     long long worst = 0;
-    for(int c = 0; c < nch; c++)
+    for(size_t i = 0; i < loops.size(); i++)
     {
-        total_hops += st[c].hops;
-        total_late += st[c].late;
-        if(st[c].worst_ms > worst) worst = st[c].worst_ms;
-        if(st[c].late) std::cerr << "ch=" << c << ": " << st[c].late << " of " << st[c].hops << " hops answered later than 210 ms (worst " << st[c].worst_ms << " ms)" << std::endl;
-        if(st[c].fd >= 0) close(st[c].fd);
+        const LoopStats& ls = loops[i]->stats();
+        total_hops += ls.hops;
+        total_late += ls.late;
+        batches += ls.batches;
+        overflowed += ls.overflowed_hops;
+        worst = std::max(worst, ls.worst_ms);
+        for(int c = 0; c < loops[i]->streams(); c++)
+        {
+            const DeviceLoop::StreamReport r = loops[i]->stream_report(c);
+            if(r.late) std::cerr << "ch=" << shares[i].first + c << ": " << r.late << " of " << r.hops << " hops answered later than 210 ms (worst " << r.worst_ms << " ms)" << std::endl;
+        }
+        if(loops.size() > 1)
+            std::cerr << "msk144hipdecoder: device " << shares[i].device << " (streams " << shares[i].first << ".." << shares[i].first + shares[i].count - 1 << "): " << ls.batches << " batches, "
+                      << ls.hops << " stream hops, " << ls.late << " late, worst latency " << ls.worst_ms << " ms" << std::endl;
     }
     std::cerr << "msk144hipdecoder: " << batches << " batches, " << total_hops << " stream hops, " << total_late << " late, worst latency " << worst << " ms" << std::endl;
+    if(overflowed) std::cerr << "msk144hipdecoder: " << overflowed << " hops overflowed the result list (lists cut, see above)" << std::endl;
     if(timing)
     {
-        const double wall_s = ms_between(ingest_since, Clock::now()) * 1e-3;
-        auto row = [](const char* name, const Accumulator& a) {
-            fprintf(stderr, "msk144hipdecoder timing: %-34s mean %9.3f ms  max %9.3f ms\n", name, a.mean(), a.worst);
-        };
-        fprintf(stderr, "msk144hipdecoder timing: %d streams, %ld batches in %.2f s wall; per batch (host wall time):\n", nch, batches, wall_s);
-        row("ingest (read syscalls, all streams)", t_ingest);
-        row("copy new hops into pinned slot", t_assemble);
-        row("submit (3 asynchronous calls)", t_submit);
-        row("wait for GPU + D2H (post thread)", t_wait);
-        row("post-processing (text, SNR, filter)", t_post);
-        row("print", t_print);
-        row("batch released -> lines printed", t_latency);
-        fprintf(stderr, "msk144hipdecoder timing: records per batch mean %.0f max %.0f\n", t_records.mean(), t_records.worst);
-        float dev[MSK144_T_COUNT];
-        if(dec.stage_times(dev))
-            fprintf(stderr, "msk144hipdecoder timing: device per batch (HIP events): H2D %.3f  front end %.3f  scan %.3f  softbits %.3f  index %.3f  LDPC %.3f  collect %.3f  D2H %.3f ms\n",
-                    dev[MSK144_T_H2D], dev[MSK144_T_FRONTEND], dev[MSK144_T_SCAN], dev[MSK144_T_SOFTBITS], dev[MSK144_T_INDEX], dev[MSK144_T_LDPC], dev[MSK144_T_COLLECT], dev[MSK144_T_D2H]);
+        const double wall_s = std::chrono::duration<double>(Clock::now() - run_since).count();
+        auto row = [](const char* name, const Accumulator& a) { fprintf(stderr, "msk144hipdecoder timing: %-34s mean %9.3f ms  max %9.3f ms\n", name, a.mean(), a.worst); };
+        for(size_t i = 0; i < loops.size(); i++)
+        {
+            const LoopStats& ls = loops[i]->stats();
+            if(loops.size() > 1) fprintf(stderr, "msk144hipdecoder timing: ---- device %d: %d streams (%d..%d), own ingest and post-processing threads ----\n", shares[i].device, shares[i].count, shares[i].first, shares[i].first + shares[i].count - 1);
+            fprintf(stderr, "msk144hipdecoder timing: %d streams, %ld batches in %.2f s wall; per batch (host wall time):\n", shares[i].count, ls.batches, loops.size() > 1 ? ls.wall_s : wall_s);
+            row("ingest (read syscalls, all streams)", ls.ingest);
+            row("copy new hops into pinned slot", ls.assemble);
+            row("submit (3 asynchronous calls)", ls.submit);
+            row("wait for GPU + D2H (post thread)", ls.wait);
+            row("post-processing (text, SNR, filter)", ls.post);
+            row("print", ls.print);
+            row("batch released -> lines printed", ls.latency);
+            fprintf(stderr, "msk144hipdecoder timing: records per batch mean %.0f max %.0f\n", ls.records.mean(), ls.records.worst);
+            const float* dev = ls.device_ms;
+            if(ls.have_device_ms)
+                fprintf(stderr, "msk144hipdecoder timing: device per batch (HIP events): H2D %.3f  front end %.3f  scan %.3f  softbits %.3f  index %.3f  LDPC %.3f  collect %.3f  D2H %.3f ms\n",
+                        dev[MSK144_T_H2D], dev[MSK144_T_FRONTEND], dev[MSK144_T_SCAN], dev[MSK144_T_SOFTBITS], dev[MSK144_T_INDEX], dev[MSK144_T_LDPC], dev[MSK144_T_COLLECT], dev[MSK144_T_D2H]);
+        }
     }
     std::cout << "Done" << std::endl;
     return 0;

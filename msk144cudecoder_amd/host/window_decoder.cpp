@@ -22,9 +22,10 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
     opt_.channels = p.channels;
     p.device = opt.device;
     // Compact-list capacity: a strong ping is accepted by many of its candidates (neighbouring bins, patterns, slots); 256 per
-    // channel on average plus 131072 is far beyond anything a real band produces; the library clamps to channels * items, and a list that did
-    // overflow is an error (MSK144_EOVERFLOW), never a silent truncation.
-    const long long cap = 256ll * p.channels + 131072;  // a one-stream handle can hold every candidate of the widest search grid
+    // channel on average plus 131072 is far beyond what the synthetic bands here produce (58 records per decoded stream at 0 dB); the
+    // library clamps to channels * items.  A hop that does overflow is reported (MSK144_EOVERFLOW -> HopTiming::overflow), its
+    // truncated list is processed and the streams keep running - the reference keeps every ResultItem and cannot fail this way.
+    const long long cap = opt.max_results > 0 ? opt.max_results : 256ll * p.channels + 131072;  // a one-stream handle can hold every candidate of the widest search grid
     p.max_results = cap > 0x7fffffff ? 0x7fffffff : static_cast<int32_t>(cap);
     if(msk144_create(&p, &handle_) != MSK144_OK)
     {
@@ -155,11 +156,12 @@ bool WindowDecoder::collect(int slot, std::vector<std::vector<FilteredResult>>& 
     const float* seg = nullptr;
     int32_t n = 0;
     const int rc = msk144_fetch_wait(handle_, slot, &results, &n, &seg);
-    if(rc != MSK144_OK)
+    if(rc != MSK144_OK && rc != MSK144_EOVERFLOW)  // on overflow the library hands back the records that fitted
     {
-        error_ = rc == MSK144_EOVERFLOW ? "more decodes in one hop than the compact result list holds" : "msk144_fetch_wait failed";
+        error_ = "msk144_fetch_wait failed";
         return false;
     }
+    last_overflow_ = rc == MSK144_EOVERFLOW;
     const auto t1 = Clock::now();
     const std::vector<int>& streams = streams_[slot];
     const size_t n_results = static_cast<size_t>(n);
@@ -208,6 +210,7 @@ bool WindowDecoder::collect(int slot, std::vector<std::vector<FilteredResult>>& 
         timing->wait_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         timing->post_ms = std::chrono::duration<double, std::milli>(Clock::now() - t1).count();
         timing->records = n;
+        timing->overflow = rc == MSK144_EOVERFLOW;
     }
     return true;
 }

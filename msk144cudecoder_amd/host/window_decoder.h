@@ -34,6 +34,7 @@ struct DecoderOptions
     bool reference_cache_quirk = false;
     bool print_bits = false;  // append the 77-bit payload to each line (debug)
     bool profile = false;     // record per-stage device times (HIP events; --timing)
+    int max_results = 0;      // --max-results: capacity of the compact decode list per hop; 0 = 256 per stream + 131072
 };
 
 // Host wall time of one hop, split the way the pipelined loop spends it.
@@ -42,6 +43,7 @@ struct HopTiming
     double wait_ms = 0.0;  // blocked until the GPU had finished the hop and its results had arrived (msk144_fetch_wait)
     double post_ms = 0.0;  // payload -> text, SNR, per-window filter
     int records = 0;
+    bool overflow = false;  // the hop held more decodes than the compact list: `records` of them were kept and processed
 };
 
 // What one accepted candidate contributes, independent of the GPU (unit-testable on the CPU).
@@ -108,6 +110,8 @@ public:
     void* stage(int slot);
     bool submit(int slot, const std::vector<int>& streams);
     bool collect(int slot, std::vector<std::vector<FilteredResult>>& lines, HopTiming* timing = nullptr);
+    // the hop collect() returned last held more decodes than the compact list (its truncated list was processed)
+    bool last_hop_overflowed() const { return last_overflow_; }
     // average device milliseconds per hop of every stage (frontend, scan, softbits, index, ldpc, collect, h2d, d2h); needs
     // DecoderOptions::profile; waits for the GPU
     bool stage_times(float out[MSK144_T_COUNT]);
@@ -123,6 +127,7 @@ private:
     std::vector<CallHashTable> calls_;
     std::vector<int> streams_[kSlots];  // streams of the hop in flight on each slot, by position
     size_t window_bytes_ = 0;           // of one stream
+    bool last_overflow_ = false;
 };
 
 }  // namespace msk144host

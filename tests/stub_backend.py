@@ -51,5 +51,20 @@ class Backend:
     def results(self):
         return self._rec.copy()
 
+    class _Mark:
+        def __init__(self):
+            import time
+            self.t = time.perf_counter()
+
+        def synchronize(self):
+            pass
+
+    def marker(self):
+        return Backend._Mark()
+
+    @staticmethod
+    def ms_between(a, b):
+        return (b.t - a.t) * 1e3
+
     def close(self):
         pass

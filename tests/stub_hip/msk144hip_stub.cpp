@@ -4,6 +4,9 @@
 // a worker thread (the asynchronous GPU) and yields one record per channel whose window's first sample is 0x7777.  Its payload is a
 // telemetry message (i3 = 0, n3 = 5: 71 bits printed as hex by the text layer) holding the channel and the second sample of each
 // window half - enough to check from stdout that every hop of every stream reached the decoder once, in order, in its own slot.
+// MSK144_STUB_DEVICES=N makes it report N devices (msk144_device_count; a handle on ordinal >= N is refused), and the device ordinal
+// of the handle that decoded a window rides in the top byte of the payload, so a test of `--devices=...` can tell which loop served
+// which stream.  A hop with more records than msk144_params.max_results is cut and reported as MSK144_EOVERFLOW, like the library.
 #include "../../include/msk144hip.h"
 
 #include <chrono>
@@ -31,8 +34,18 @@ struct msk144_handle
     int cur = 0;
     int active[MSK144_SLOTS] = {0, 0};  // windows the hop in each slot covers
     int decode_ms = 5;
+    bool overflow[MSK144_SLOTS] = {false, false};
     std::string error;
 };
+
+static int stub_devices()
+{
+    const char* e = std::getenv("MSK144_STUB_DEVICES");
+    const int n = e ? std::atoi(e) : 1;
+    return n < 1 ? 1 : n;
+}
+
+static thread_local std::string g_create_error = "stub";
 
 extern "C" {
 
@@ -49,8 +62,26 @@ void msk144_default_params(msk144_params* p)
     p->channels = 1;
 }
 
+int msk144_device_count(int32_t* n)
+{
+    *n = stub_devices();
+    return MSK144_OK;
+}
+
+int msk144_clock_probe(msk144_handle*, int32_t, float* mhz)
+{
+    *mhz = 0.0f;
+    return MSK144_OK;
+}
+
 int msk144_create(const msk144_params* p, msk144_handle** out)
 {
+    if(p->device < 0 || p->device >= stub_devices())
+    {
+        g_create_error = "device ordinal out of range";
+        *out = nullptr;
+        return MSK144_EINVAL;
+    }
     auto* h = new msk144_handle();
     h->p = *p;
     if(const char* e = std::getenv("MSK144_STUB_DECODE_MS")) h->decode_ms = std::atoi(e);
@@ -66,7 +97,7 @@ void msk144_destroy(msk144_handle* h)
     delete h;
 }
 
-const char* msk144_last_error(const msk144_handle* h) { return h ? h->error.c_str() : "stub"; }
+const char* msk144_last_error(const msk144_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
 int msk144_geometry(const msk144_handle* h, int32_t* f, int32_t* d, int32_t* k)
 {
@@ -194,7 +225,7 @@ int msk144_fetch_async(msk144_handle* h, int32_t s)
             r.channel = c;
             r.item = c;
             r.f0 = 1500.0f;
-            const uint64_t v = (static_cast<uint64_t>(c) << 32) | (static_cast<uint64_t>(static_cast<uint16_t>(w[1])) << 16) |
+            const uint64_t v = (static_cast<uint64_t>(h->p.device & 0xff) << 56) | (static_cast<uint64_t>(c) << 32) | (static_cast<uint64_t>(static_cast<uint16_t>(w[1])) << 16) |
                                static_cast<uint16_t>(w[MSK144_HOP_SAMPLES + 1]);
             uint8_t bits[80] = {0};
             for(int i = 0; i < 64; i++) bits[7 + i] = (v >> (63 - i)) & 1u;  // 71-bit field, MSB first: 7 leading zeros + 64 bits
@@ -203,6 +234,8 @@ int msk144_fetch_async(msk144_handle* h, int32_t s)
             for(int i = 0; i < 80; i++) r.message[i / 8] |= static_cast<uint8_t>(bits[i] << (7 - (i % 8)));
             h->out[s].push_back(r);
         }
+        h->overflow[s] = h->p.max_results > 0 && h->out[s].size() > static_cast<size_t>(h->p.max_results);
+        if(h->overflow[s]) h->out[s].resize(static_cast<size_t>(h->p.max_results));
         done.set_value();
     });
     return MSK144_OK;
@@ -216,7 +249,7 @@ int msk144_fetch_wait(msk144_handle* h, int32_t s, const msk144_result** rec, in
     *rec = h->out[s].data();
     *n = static_cast<int32_t>(h->out[s].size());
     if(seg) *seg = h->seg[s].data();
-    return MSK144_OK;
+    return h->overflow[s] ? MSK144_EOVERFLOW : MSK144_OK;
 }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ def _run(extra, env_extra=None, timeout=300):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--channels", "8",
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--channels", "8", "--sustain-seconds", "0.2",
                            "--backend-module", "stub_backend"] + extra, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
@@ -36,6 +36,10 @@ def test_gpus2_self_launch_reports_two_ranks():
     assert len(rk["per_rank"]) == 2 and rk["min"] <= rk["max"] and abs(rk["max"] - out["ms_per_step"]) < 1e-6
     assert g["ms_per_step"] is not None and g["ms_per_step"] >= 0.0
     assert "roofline" in out and out["roofline"]["mode"]
+    # the sustained leg: the same step run on after the timed region, the same number of steps on every rank (the gather is a collective)
+    su = out["sustained"]
+    assert su["steps"] >= 150 and set(su["ms_per_step"]) == {"first50", "mid50", "last50", "all"} and su["drift_last_vs_first"] is not None
+    assert su["clock_mhz"] is None                    # the stub has no GPU to probe
 
 
 def test_gpus8_self_launch_on_gloo():

@@ -320,3 +320,49 @@ def test_paced_fifos_one_stalled_stream_does_not_hold_the_batch(tmp_path):
     assert hops == n_ch * (n_hops + 1)                      # nothing dropped
     assert batches > n_hops + 1                             # the stalled stream was served in batches of its own
     assert late == 0 and worst <= 210, err[-1500:]          # no stream waited on the stalled one beyond the soft limit
+
+
+def test_cli_two_device_loops_on_one_gpu_equal_separate_runs(tmp_path):
+    """--devices=0,0: two device loops - two live library handles, two ingest and two post-processing threads,
+    one printer - over six streams on the one GPU of the box.  Streams 0..2 belong to the first loop, 3..5 to the second, ch= is the
+    global stream number, and every stream's lines are byte-identical (date= aside) to two separate single-device runs over the two
+    halves.  On an 8-GPU node the same code path runs with eight different ordinals (main.cu:115 binds the reference to one)."""
+    rng = np.random.default_rng(90)
+    args = ["--search-width=16", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2", "--print-bits"]
+    texts = [("CQ", "K1ABC", "FN42"), None, ("K1ABC", "W9XYZ", "-11"), ("CQ", "DL1ABC", "JO62"), ("W9XYZ", "K1ABC", "R-09"), None]
+    files = []
+    for i, n_hops in enumerate((4, 2, 5, 3, 6, 1)):
+        pings = [] if texts[i] is None else [synth.Ping(pack77.pack_standard(*texts[i]), 900 + 1500 * (i % 4), 6, 1496.0 + 2 * i, 5.0, 0.3 * i)]
+        stream = synth.synth_audio(5184 + n_hops * 2592, pings, 1000.0, rng)
+        path = tmp_path / f"s{i}.s16"
+        path.write_bytes(stream.tobytes())
+        files.append(str(path))
+
+    def by_channel(out, offset=0):
+        per = {}
+        lines = out.strip().split("\n")
+        assert lines[-1] == "Done" and out.count("Done") == 1
+        for l in lines[:-1]:
+            m = re.match(r"^\*\*\*  ch=(\d+); (.*)$", l)
+            assert m, l
+            per.setdefault(offset + int(m.group(1)), []).append(re.sub(r"date=\d{14}", "date=X", m.group(2)))
+        return per
+
+    rc, out, err = _run(args + ["--devices=0,0", "--timing", "--inputs=" + ",".join(files)], b"")
+    assert rc == 0, err
+    both = by_channel(out)
+    assert "device 0 decodes streams 0..2" in err and "device 0 decodes streams 3..5" in err and err.count("---- device 0: 3 streams") == 2
+    assert err.count("Incomplete read error") == 6
+    want = {}
+    for half in (0, 1):
+        rc, out1, err1 = _run(args + ["--inputs=" + ",".join(files[3 * half:3 * half + 3])], b"")
+        assert rc == 0, err1
+        want.update(by_channel(out1, 3 * half))
+    assert both == want and set(both) == {0, 2, 3, 4}                     # the four streams that carry a ping, nothing on the noise streams
+    for c, t in ((0, "CQ K1ABC FN42"), (2, "K1ABC W9XYZ -11"), (3, "CQ DL1ABC JO62"), (4, "W9XYZ K1ABC R-09")):
+        assert all(f"msg='{t}'" in l for l in both[c])
+    m = re.search(r"msk144hipdecoder: (\d+) batches, (\d+) stream hops", err)
+    assert int(m.group(2)) == sum(h + 1 for h in (4, 2, 5, 3, 6, 1))
+    # an ordinal the box does not have is refused before anything runs
+    rc, out, err = _run(args + ["--devices=0,99", "--inputs=" + ",".join(files)], b"")
+    assert rc == 2 and "device 99" in err

@@ -247,3 +247,64 @@ def test_device_side_hop_ring_equals_host_windows(hip, read_mode):
     for (r0, p0), (r1, p1), members in zip(want, got, schedule):
         assert r0.tobytes() == r1.tobytes()
         assert np.array_equal(p0[:len(members)].view(np.uint32), p1[:len(members)].view(np.uint32))
+
+
+def test_two_live_handles_decode_concurrently_from_two_threads(hip):
+    """Handles are independent (include/msk144hip.h; the multi-device stream program keeps one per GPU, each driven by its own
+    threads): two handles alive at once, each decoding its own six hops through its slots from its own thread at the same time, with
+    different channel counts and channel bases, must return exactly what each returns when it runs alone.  Also the new ABI entries:
+    msk144_device_count >= 1 and a plausible shader clock from msk144_clock_probe while a decode is in flight."""
+    assert hip.device_count() >= 1
+    sets = [(_windows(6, 10, 31), 10, 0), (_windows(6, 7, 32), 7, 1000)]
+    refs = []
+    for wins, channels, base in sets:
+        ref = []
+        with hip.HipDecoder(channels=channels, max_results=1 << 16, **CFG) as d:
+            d.set_channel_base(base)
+            for w in wins:
+                d.submit_audio(w)
+                d.decode()
+                ref.append(d.results().copy())
+        refs.append(ref)
+    assert all(sum(len(r) for r in ref) > 10 for ref in refs)
+    got = [[], []]
+    errors = []
+    start = threading.Barrier(2)
+    decs = [hip.HipDecoder(channels=channels, max_results=1 << 16, **CFG) for _, channels, _ in sets]
+    clocks = []
+
+    def work(k):
+        try:
+            d = decs[k]
+            wins, _, base = sets[k]
+            d.set_channel_base(base)
+            start.wait()
+            for n, w in enumerate(wins):
+                s = n % 2
+                d.input_slot(s)[:] = w
+                d.submit_slot(s)
+                d.decode()
+                d.fetch_async(s)
+                if k == 0 and n == 2:
+                    clocks.append(d.clock_probe(500))
+                if n >= 1:
+                    got[k].append(d.fetch_wait(1 - s)[0].copy())
+            got[k].append(d.fetch_wait((len(wins) - 1) % 2)[0].copy())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for d in decs:
+        d.close()
+    assert not errors, errors
+    for k in range(2):
+        assert len(got[k]) == len(refs[k])
+        for a, b in zip(refs[k], got[k]):
+            assert a.tobytes() == b.tobytes()
+        base = sets[k][2]
+        assert all(((r["channel"] >= base) & (r["channel"] < base + sets[k][1])).all() for r in got[k] if len(r))
+    assert clocks and 500.0 < clocks[0] < 3000.0, clocks

@@ -15,6 +15,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "msk144cudecoder_amd", "host")
+PROGRAM_SOURCES = ("snr_tracker.cpp", "result_filter.cpp", "unpack77.cpp", "postprocess.cpp", "window_decoder.cpp", "stream_loop.cpp", "main.cpp")
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +23,7 @@ def exe(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("stubhip"))
     subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", os.path.join(d, "libmsk144hip.so"),
                     os.path.join(ROOT, "tests", "stub_hip", "msk144hip_stub.cpp")], check=True)
-    srcs = [os.path.join(HOST, f) for f in ("snr_tracker.cpp", "result_filter.cpp", "unpack77.cpp", "postprocess.cpp", "window_decoder.cpp", "main.cpp")]
+    srcs = [os.path.join(HOST, f) for f in PROGRAM_SOURCES]
     out = os.path.join(d, "msk144hipdecoder_stub")
     subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-pthread", "-o", out] + srcs + ["-L" + d, "-lmsk144hip", "-Wl,-rpath," + d], check=True)
     return out
@@ -38,8 +39,9 @@ def marked_stream(n_hops, tag):
     return x
 
 
-def windows_seen(stdout, n_streams):
-    """{channel: [(first half id, second half id), ...]} in output order, from the telemetry text of the stub's records."""
+def windows_seen(stdout, n_streams, devices=None):
+    """{channel: [(first half id, second half id), ...]} in output order, from the telemetry text of the stub's records.
+    `devices` (a dict) receives {channel: set of device ordinals whose handle decoded it}."""
     seen = {c: [] for c in range(n_streams)}
     for line in stdout.strip().split("\n"):
         if line == "Done":
@@ -49,6 +51,8 @@ def windows_seen(stdout, n_streams):
         v = int(m.group(2), 16)
         ch = int(m.group(1) or 0)     # the stream the host attributes the record to; v >> 32 is only its position in the compact batch
         seen[ch].append(((v >> 16) & 0xFFFF, v & 0xFFFF))
+        if devices is not None:
+            devices.setdefault(ch, set()).add(v >> 56)
     return seen
 
 
@@ -145,11 +149,149 @@ def test_many_streams_unpaced_through_the_scale_harness(exe):
     old = host_scale.EXE
     host_scale.EXE = exe
     os.environ["MSK144_STUB_DECODE_MS"] = "20"
+    os.environ["MSK144_STUB_DEVICES"] = "2"
     try:
         res = host_scale.run(256, 12, pace_ms=0.0, timeout_s=60.0)
+        two = host_scale.run(128, 6, pace_ms=20.0, timeout_s=60.0, devices="0,1", phase_spread_ms=15.0)
     finally:
+        del os.environ["MSK144_STUB_DEVICES"]
         host_scale.EXE = old
         del os.environ["MSK144_STUB_DECODE_MS"]
     assert res["returncode"] == 0 and res["feeder_errors"] == 0, res
     assert res["stream_hops"] == 256 * 13
     assert res["host_ms_per_batch"]["wait for GPU + D2H (post thread)"]["mean_ms"] >= 15.0
+    # --devices: one timing block per device loop
+    assert two["returncode"] == 0 and two["stream_hops"] == 128 * 7 and len(two["per_device"]) == 2, two
+    assert [d["streams"] for d in two["per_device"]] == [64, 64] and two["per_device"][1]["first_stream"] == 64
+    assert all("ingest (read syscalls, all streams)" in d["host_ms_per_batch"] for d in two["per_device"])
+
+
+def _feed_fifos(paths, data, chunk=5184):
+    """Writer threads: every FIFO gets its stream in hop-sized writes, as fast as the pipe takes them."""
+    def feed(lo, hi):
+        fds = [os.open(paths[c], os.O_WRONLY) for c in range(lo, hi)]
+        off = 0
+        n = max(len(data[c]) for c in range(lo, hi))
+        while off < n:
+            for k, c in enumerate(range(lo, hi)):
+                if off < len(data[c]):
+                    os.write(fds[k], data[c][off:off + chunk])
+            off += chunk
+        for fd in fds:
+            os.close(fd)
+    per = -(-len(paths) // 8)
+    ths = [threading.Thread(target=feed, args=(k * per, min(len(paths), (k + 1) * per))) for k in range(8) if k * per < len(paths)]
+    for t in ths:
+        t.start()
+    return ths
+
+
+def _run_fifos(exe, tmp_path, tag, data, args, env):
+    paths = [str(tmp_path / f"{tag}_{c}.fifo") for c in range(len(data))]
+    for p in paths:
+        os.mkfifo(p)
+    lst = tmp_path / f"{tag}.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    proc = subprocess.Popen([exe, f"--inputs-file={lst}"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    ths = _feed_fifos(paths, data)
+    out, err = proc.communicate(timeout=120)
+    for t in ths:
+        t.join()
+    return proc.returncode, out.decode(), err.decode()
+
+
+def _lines_by_channel(stdout, offset=0):
+    per = {}
+    for line in stdout.strip().split("\n")[:-1]:
+        ch = int(re.match(r"^\*\*\*  ch=(\d+); ", line).group(1))
+        per.setdefault(offset + ch, []).append(re.sub(r"date=\d+; ", "", re.sub(r"ch=\d+; ", "", line, count=1)))   # date= is wall-clock time
+    return per
+
+
+def test_four_devices_equal_four_single_device_runs(exe, tmp_path):
+    """--devices=0,1,2,3 over 4 x 64 FIFOs (the stub reports four devices): every stream is served by the loop of its own device,
+    ch= is the global stream number, and each stream's lines are exactly those of a single-device run over that device's 64 streams."""
+    n, hops = 256, 6
+    data = [marked_stream(hops + (c % 3), 7 * c).tobytes() for c in range(n)]
+    env = dict(os.environ, MSK144_STUB_DECODE_MS="6", MSK144_STUB_DEVICES="4")
+    rc, out, err = _run_fifos(exe, tmp_path, "all", data, ["--devices=0,1,2,3", "--timing"], env)
+    assert rc == 0, err[-2000:]
+    devs = {}
+    seen = windows_seen(out, n, devs)
+    for c in range(n):
+        assert seen[c] == [(7 * c + k, 7 * c + k + 1) for k in range(hops + (c % 3) + 1)], c
+        assert devs[c] == {c // 64}, (c, devs[c])                       # contiguous shares: streams 64d .. 64d+63 on device d
+    assert out.strip().endswith("Done") and out.count("Done") == 1
+    for d in range(4):
+        assert f"device {d} decodes streams {64 * d}..{64 * d + 63}" in err
+        assert f"---- device {d}: 64 streams ({64 * d}..{64 * d + 63})" in err
+    m = re.search(r"msk144hipdecoder: (\d+) batches, (\d+) stream hops, (\d+) late", err)
+    assert m and int(m.group(2)) == sum(hops + (c % 3) + 1 for c in range(n))
+    per_channel = _lines_by_channel(out)
+    for d in range(4):
+        rc1, out1, err1 = _run_fifos(exe, tmp_path, f"dev{d}", data[64 * d:64 * (d + 1)], [f"--device={d}"], env)
+        assert rc1 == 0, err1[-2000:]
+        single = _lines_by_channel(out1, 64 * d)
+        for c in range(64 * d, 64 * (d + 1)):
+            assert per_channel[c] == single[c], c
+
+
+def test_devices_option_errors_and_interleaved_split(exe, tmp_path):
+    r = subprocess.run([exe, "--devices=0,1"], input=b"", capture_output=True, timeout=60, env=dict(os.environ, MSK144_STUB_DEVICES="2"))
+    assert r.returncode == 2 and "--devices splits the streams" in r.stderr.decode()
+    p = tmp_path / "a.s16"
+    p.write_bytes(marked_stream(2, 1).tobytes())
+    r = subprocess.run([exe, f"--inputs={p},{p}", "--devices=0,5"], capture_output=True, timeout=60, env=dict(os.environ, MSK144_STUB_DEVICES="2"))
+    assert r.returncode == 2 and "device 5: device ordinal out of range" in r.stderr.decode()
+    # more devices than streams: the surplus devices get no loop; --devices=all asks the library
+    r = subprocess.run([exe, f"--inputs={p},{p}", "--devices=all"], capture_output=True, timeout=60, env=dict(os.environ, MSK144_STUB_DEVICES="3"))
+    assert r.returncode == 0 and "device 2 decodes" not in r.stderr.decode() and "device 1 decodes streams 1..1" in r.stderr.decode()
+    # --interleaved=5 over two devices: streams 0..2 on device 0, 3..4 on device 1, one reader splitting every block
+    n, hops = 5, 6
+    streams = [marked_stream(hops, 300 * c) for c in range(n)]
+    blocks = [np.stack([s[:5184] for s in streams]).tobytes()] + [np.stack([s[5184 + h * 2592:5184 + (h + 1) * 2592] for s in streams]).tobytes() for h in range(hops)]
+    r = subprocess.run([exe, f"--interleaved={n}", "--devices=0,1"], input=b"".join(blocks) + b"\0" * 64, capture_output=True, timeout=60,
+                       env=dict(os.environ, MSK144_STUB_DECODE_MS="5", MSK144_STUB_DEVICES="2"))
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    devs = {}
+    seen = windows_seen(r.stdout.decode(), n, devs)
+    for c in range(n):
+        assert seen[c] == [(300 * c + k, 300 * c + k + 1) for k in range(hops + 1)], c
+        assert devs[c] == {0 if c < 3 else 1}
+    assert f"{n * (hops + 1)} stream hops" in r.stderr.decode() and "Incomplete read error. rc=32" in r.stderr.decode()
+
+
+def test_result_list_overflow_is_reported_not_fatal(exe, tmp_path):
+    """one busy hop must not kill every stream.  --max-results=2 with five streams that all 'decode' every hop: each hop
+    is cut to two records and reported, the loop keeps running to the end of every stream and exits 0."""
+    paths = []
+    for c in range(5):
+        p = tmp_path / f"s{c}.s16"
+        p.write_bytes(marked_stream(4, 100 * c).tobytes())
+        paths.append(str(p))
+    r = subprocess.run([exe, "--max-results=2", "--inputs=" + ",".join(paths)], capture_output=True, timeout=60, env=dict(os.environ, MSK144_STUB_DECODE_MS="2"))
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-1500:]
+    seen = windows_seen(r.stdout.decode(), 5)
+    assert [len(seen[c]) for c in range(5)] == [5, 5, 0, 0, 0]              # the records that fitted were processed
+    assert err.count("the list was cut, decoding goes on") == 5 and "5 hops overflowed the result list" in err
+    assert "5 batches, 25 stream hops" in err
+
+
+def test_fifo_writer_that_leaves_without_writing_ends_its_stream_at_once(exe, tmp_path):
+    """a writer that opens and closes without a byte used to count as 'not connected yet' for the whole connect timeout
+    (10 s), holding every batch for the linger.  poll() reports its hang-up; the stream ends, the other one is decoded in full."""
+    paths = [str(tmp_path / "empty.fifo"), str(tmp_path / "full.fifo")]
+    for p in paths:
+        os.mkfifo(p)
+    proc = subprocess.Popen([exe, "--connect-timeout-ms=30000", "--inputs=" + ",".join(paths)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, MSK144_STUB_DECODE_MS="3"))
+    t0 = time.monotonic()
+    os.close(os.open(paths[0], os.O_WRONLY))
+    with open(paths[1], "wb", buffering=0) as f:
+        f.write(marked_stream(5, 40).tobytes())
+    out, err = proc.communicate(timeout=25)                                  # well inside the 30 s connect timeout
+    assert proc.returncode == 0 and time.monotonic() - t0 < 20, err.decode()[-1000:]
+    seen = windows_seen(out.decode(), 2)
+    assert seen[0] == [] and seen[1] == [(40 + k, 41 + k) for k in range(6)]
+    assert "ch=0: Incomplete read error. rc=0" in err.decode()

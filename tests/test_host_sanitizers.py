@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from test_host_loop import HOST, ROOT, marked_stream, windows_seen
+from test_host_loop import HOST, PROGRAM_SOURCES, ROOT, marked_stream, windows_seen
 
 
 def _build(tmp, flag):
@@ -17,7 +17,7 @@ def _build(tmp, flag):
                        capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip(f"-fsanitize={flag} not usable with this toolchain: {r.stderr[-200:]}")
-    srcs = [os.path.join(HOST, f) for f in ("snr_tracker.cpp", "result_filter.cpp", "unpack77.cpp", "postprocess.cpp", "window_decoder.cpp", "main.cpp")]
+    srcs = [os.path.join(HOST, f) for f in PROGRAM_SOURCES]
     exe = os.path.join(d, "msk144hipdecoder_san")
     subprocess.run(common + ["-ffp-contract=off", "-o", exe] + srcs + ["-L" + d, "-lmsk144hip", "-Wl,-rpath," + d], check=True)
     return exe
@@ -42,6 +42,19 @@ def test_multi_stream_loop_under_sanitizers(tmp_path, flag):
     streams = [marked_stream(h, 10 * c) for c in range(n)]
     blocks = [np.stack([s[:5184] for s in streams]).tobytes()] + [np.stack([s[5184 + k * 2592:5184 + (k + 1) * 2592] for s in streams]).tobytes() for k in range(h)]
     r = subprocess.run([exe, f"--interleaved={n}"], input=b"".join(blocks), capture_output=True, timeout=300, env=env)
+    err = r.stderr.decode()
+    assert r.returncode == 0 and "Sanitizer" not in err and "runtime error" not in err, err[-3000:]
+    assert windows_seen(r.stdout.decode(), n)[3] == [(30 + k, 31 + k) for k in range(h + 1)]
+    # three device loops side by side (six threads, one printer), files of different length; then interleaved stdin split over two
+    env3 = dict(env, MSK144_STUB_DEVICES="3")
+    r = subprocess.run([exe, "--timing", "--devices=0,1,2", "--inputs=" + ",".join(paths)], capture_output=True, timeout=300, env=env3)
+    err = r.stderr.decode()
+    assert r.returncode == 0 and "Sanitizer" not in err and "runtime error" not in err, err[-3000:]
+    devs = {}
+    seen = windows_seen(r.stdout.decode(), len(hops), devs)
+    for c, hh in enumerate(hops):
+        assert seen[c] == [(50 * c + k, 50 * c + k + 1) for k in range(hh + 1)] and devs[c] == {c // 2}, c
+    r = subprocess.run([exe, f"--interleaved={n}", "--devices=0,1"], input=b"".join(blocks), capture_output=True, timeout=300, env=env3)
     err = r.stderr.decode()
     assert r.returncode == 0 and "Sanitizer" not in err and "runtime error" not in err, err[-3000:]
     assert windows_seen(r.stdout.decode(), n)[3] == [(30 + k, 31 + k) for k in range(h + 1)]

@@ -50,7 +50,23 @@ def make_streams(n_streams: int, n_hops: int, seed: int = 7):
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16), sent
 
 
-def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = None, timeout_s: float = 180.0):
+def parse_timing(err: str):
+    """{row: {mean_ms, max_ms}} and the device-side split from one --timing block of the program's stderr."""
+    rows = {}
+    for name, mean, worst in re.findall(r"timing: (.+?)\s+mean\s+([\d.]+) ms\s+max\s+([\d.]+) ms", err):
+        rows[name.strip()] = {"mean_ms": float(mean), "max_ms": float(worst)}
+    dev = None
+    m = re.search(r"device per batch \(HIP events\): (.*) ms", err)
+    if m:
+        dev = {k.strip(): float(v) for k, v in re.findall(r"([A-Za-z0-9 ]+?)\s+([\d.]+)(?:\s{2}|$)", m.group(1))}
+    return rows, dev
+
+
+def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = None, timeout_s: float = 180.0, devices: str = None,
+        phase_spread_ms: float = 0.0):
+    """devices: value for --devices (e.g. "0,0" or "0,1,2,3"): one ingest+post thread pair per entry, per-device rows in the result.
+    phase_spread_ms: every feeder thread's hop clock is offset by a fixed random phase in [0, phase_spread_ms) - streams that are NOT
+    phase-aligned (real receivers are not), instead of all hops falling due together."""
     import resource
     soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
     if soft < n_streams + 256:
@@ -63,7 +79,8 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
     lst = os.path.join(tmp, "inputs.txt")
     with open(lst, "w") as f:
         f.write("\n".join(paths) + "\n")
-    cmd = [EXE] + DEEP + ["--print-bits", "--timing", f"--inputs-file={lst}"] + ([f"--hop-timeout-ms={hop_timeout_ms}"] if hop_timeout_ms is not None else []) + list(extra_args)
+    cmd = [EXE] + DEEP + ["--print-bits", "--timing", f"--inputs-file={lst}"] + ([f"--hop-timeout-ms={hop_timeout_ms}"] if hop_timeout_ms is not None else []) + \
+        ([f"--devices={devices}"] if devices else []) + list(extra_args)
     out_path, err_path = os.path.join(tmp, "stdout.txt"), os.path.join(tmp, "stderr.txt")
     with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
         proc = subprocess.Popen(cmd, stdout=fo, stderr=fe)
@@ -90,12 +107,17 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
         t0 = time.monotonic()
         start = threading.Barrier(feeders)
 
+        phases = np.random.default_rng(11).uniform(0.0, phase_spread_ms * 1e-3, size=feeders) if phase_spread_ms > 0 else np.zeros(feeders)
+
         def feed(lo, hi):
             try:
                 start.wait()
+                phase = float(phases[lo // per])
+                if phase > 0:
+                    time.sleep(phase)
                 for h in range(-1, n_hops):
                     if h >= 0 and pace_ms > 0:
-                        time.sleep(max(0.0, t0 + 0.5 + pace_ms * 1e-3 * (h + 1) - time.monotonic()))
+                        time.sleep(max(0.0, t0 + 0.5 + phase + pace_ms * 1e-3 * (h + 1) - time.monotonic()))
                     a, b = (0, 5184 * 2) if h < 0 else (5184 * 2 + h * 5184, 5184 * 2 + (h + 1) * 5184)
                     for c in range(lo, hi):
                         os.write(fds[c], raw[c, a:b].tobytes())
@@ -130,16 +152,27 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
     os.rmdir(tmp)
     res = {"streams": n_streams, "hops_per_stream": n_hops + 1, "pace_ms": pace_ms, "returncode": rc, "feeder_errors": len(errors), "wall_s": round(wall, 3),
            "options": " ".join(DEEP), "lines": out.count("\n") - 1}
-    m = re.search(r"(\d+) batches, (\d+) stream hops, (\d+) late, worst latency (\d+) ms", err)
+    m = re.search(r"msk144hipdecoder: (\d+) batches, (\d+) stream hops, (\d+) late, worst latency (\d+) ms", err)   # the total line (per-device lines name their device first)
     if m:
         res.update(batches=int(m.group(1)), stream_hops=int(m.group(2)), late_hops=int(m.group(3)), worst_latency_ms=int(m.group(4)))
-    rows = {}
-    for name, mean, worst in re.findall(r"timing: (.+?)\s+mean\s+([\d.]+) ms\s+max\s+([\d.]+) ms", err):
-        rows[name.strip()] = {"mean_ms": float(mean), "max_ms": float(worst)}
-    res["host_ms_per_batch"] = rows
-    m = re.search(r"device per batch \(HIP events\): (.*) ms", err)
-    if m:
-        res["device_ms_per_batch"] = {k.strip(): float(v) for k, v in re.findall(r"([A-Za-z0-9 ]+?)\s+([\d.]+)(?:\s{2}|$)", m.group(1))}
+    sections = re.split(r"timing: ---- device ", err)
+    if len(sections) > 1:
+        # --devices: one block per device loop (its own ingest and post-processing threads)
+        res["devices"] = devices
+        res["per_device"] = []
+        for sec in sections[1:]:
+            m = re.match(r"(\d+): (\d+) streams \((\d+)\.\.(\d+)\)", sec)
+            rows, dev = parse_timing(sec)
+            mb = re.search(r"timing: \d+ streams, (\d+) batches in ([\d.]+) s wall", sec)
+            res["per_device"].append({"device": int(m.group(1)), "streams": int(m.group(2)), "first_stream": int(m.group(3)), "batches": int(mb.group(1)) if mb else None,
+                                      "host_ms_per_batch": rows, "device_ms_per_batch": dev})
+        res["host_ms_per_batch"] = res["per_device"][0]["host_ms_per_batch"]
+    else:
+        rows, dev = parse_timing(err)
+        res["host_ms_per_batch"] = rows
+        if dev:
+            res["device_ms_per_batch"] = dev
+    res["phase_spread_ms"] = phase_spread_ms
     decoded = {}
     for ch, bits in re.findall(r"ch=(\d+); .*?bits='([01]{77})'", out):
         decoded.setdefault(int(ch), set()).add(bits)
@@ -156,8 +189,11 @@ def main():
     ap.add_argument("--hops", type=int, default=20)
     ap.add_argument("--pace-ms", type=float, default=216.0)
     ap.add_argument("--hop-timeout-ms", type=int, default=None, help="default: the decoder's own (20 ms)")
+    ap.add_argument("--devices", default=None, help="passed to the decoder as --devices=... (one loop per entry; an ordinal may repeat)")
+    ap.add_argument("--phase-spread-ms", type=float, default=0.0, help="spread the feeders' hop clocks over this many ms instead of phase-aligning every stream")
+    ap.add_argument("--feeders", type=int, default=8)
     a = ap.parse_args()
-    print(json.dumps(run(a.streams, a.hops, a.pace_ms, hop_timeout_ms=a.hop_timeout_ms)), flush=True)
+    print(json.dumps(run(a.streams, a.hops, a.pace_ms, hop_timeout_ms=a.hop_timeout_ms, devices=a.devices, phase_spread_ms=a.phase_spread_ms, feeders=a.feeders)), flush=True)
 
 
 if __name__ == "__main__":
