@@ -124,12 +124,18 @@ class HipBackend:
         self.T_NAMES = T_NAMES
         torch.cuda.set_device(local_rank)
         self.device = torch.device("cuda", local_rank)
+        # ONE explicit stream carries everything of this rank - decode kernels, timing markers, the copy into the gather's send
+        # buffer, and the collective joins it: torch's default stream is the null stream (handle 0, which the library reads as
+        # "use your own stream"), and a non-blocking stream is not ordered against it.
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.stream)
         self.wins_host, self.truth = make_inputs(rank, channels)
         self.wins_dev = torch.from_numpy(self.wins_host).cuda(local_rank)   # inputs resident in HBM before timing
         self.dec = HipDecoder(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, read_mode=1,
                               analytic_method=2, channels=channels, device=local_rank, max_results=1 << 20, llr_block_channels=llr_block)
         self.llr_block = self.dec.params.llr_block_channels or min(channels, 64)
-        self.dec.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert self.stream.cuda_stream != 0
+        self.dec.set_stream(self.stream.cuda_stream)
         self.dec.set_channel_base(channel_base)
         self.channel_base = channel_base
         self.F, self.D, self.K = self.dec.F, self.dec.D, self.dec.K
@@ -424,7 +430,6 @@ def run_worker(args) -> int:
         elapsed = max(float(x.item()) for x in every)            # MAX over ranks
 
     stage = be.stage_times()
-    last = be.results()
 
     sustained = None
     if args.sustain_seconds > 0 and hasattr(be, "marker"):
@@ -432,6 +437,7 @@ def run_worker(args) -> int:
         sustained = sustained_leg(be, step, fence, n_sus, args.warmup + args.steps)
         st2 = be.stage_times()      # averages over the timed region AND the sustained leg (profiling stayed on)
         sustained["stage_ms_incl_timed_region"] = {n: round(st2[n][0], 4) for n in be.T_NAMES}
+    last = be.results()         # of the last step run (the sustained leg's when there is one): what the last gather must have carried
     # Payloads that are not the channel's transmitted message.  The reference algorithm accepts on CRC-13
     # + < 18 hard errors, so at 1.6e7 BP attempts per step a few false positives are expected; they are
     # the oracle's too (tests/test_gpu_full.py), not decoder errors.

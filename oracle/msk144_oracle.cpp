@@ -28,6 +28,34 @@ inline C cadd(C x, C y) { return {x.re + y.re, x.im + y.im}; }                  
 inline C cmul(C x, C y) { return {x.re * y.re - x.im * y.im, x.re * y.im + x.im * y.re}; }               // :54-57
 inline C smul(float m, C z) { return {m * z.re, m * z.im}; }                                             // :59-62
 inline C cconj(C z) { return {z.re, -z.im}; }                                                            // :64-67
+
+// ---- contraction bracket (tests/test_oracle_fma_bracket.py) ----
+// The reference's CUDA build contracts a*b+c into FMAs in DEVICE code (nvcc's default -fmad=true; CMakeLists.txt:130-132 adds only
+// an optional fast-math switch); its host code is plain x86-64 without FMA.  The parity build of this oracle contracts nothing
+// (-ffp-contract=off), so "bit-exact with the oracle" means bit-exact with a build that never ran on NVIDIA hardware.  Two more
+// builds of this same file bracket what the real binary may compute (oracle/Makefile, target `fma`):
+//   * libmsk144_oracle_contract.so: -ffp-contract=fast -mfma - gcc fuses every single-use product into the add or subtract that
+//     consumes it, everywhere (host-side restatements included: an over-approximation);
+//   * libmsk144_oracle_fmaf.so: -DORC_FORCE_FMA - the device-side complex products and the three accumulate hot spots
+//     (analytic2.cuh:163-219 FIR, scan_kernel.cuh:106-122 correlation, softbits_kernel.cuh:157-180 matched filter) written as the
+//     FULLY fused chains an aggressively fusing backend emits (NVPTX enables aggressive FMA fusion: s + x*y over complex numbers
+//     becomes fma(x.re, y.re, fma(-x.im, y.im, s.re))).
+// The *_dev helpers mark the device-side sites; host-side sites (SNR tracker, FFT stand-in) keep cmul/smul.
+#ifdef ORC_FORCE_FMA
+inline C cmul_dev(C x, C y) { return {fmaf(x.re, y.re, -(x.im * y.im)), fmaf(x.re, y.im, x.im * y.re)}; }
+inline C cmac_dev(C s, C x, C y) { return {fmaf(x.re, y.re, fmaf(-x.im, y.im, s.re)), fmaf(x.re, y.im, fmaf(x.im, y.re, s.im))}; }
+inline C smac_dev(C s, float m, C z) { return {fmaf(m, z.re, s.re), fmaf(m, z.im, s.im)}; }
+inline float mac_dev(float s, float a, float b) { return fmaf(a, b, s); }
+#else
+inline C cmul_dev(C x, C y) { return cmul(x, y); }
+inline C cmac_dev(C s, C x, C y) { return cadd(s, cmul(x, y)); }
+inline C smac_dev(C s, float m, C z) { return cadd(s, smul(m, z)); }
+inline float mac_dev(float s, float a, float b) { return s + a * b; }
+#endif
+#ifndef ORC_VARIANT_NAME
+#define ORC_VARIANT_NAME "parity"
+#endif
+const char* const kBuildVariant = ORC_VARIANT_NAME;  // named by the Makefile target that set the flags
 inline C from_phi(float phi)                                                                             // :79-85
 {
     float s, c;
@@ -74,7 +102,7 @@ void mix_window(const orc_ctx* ctx, int b, const orc_complex* cdat, C* cdat2, fl
     {
         const float phi = static_cast<float>(n) * twopi * f0 / kSampleRate;
         C w = from_phi(phi);
-        cdat2[n] = cmul(w, C{cdat[n].re, cdat[n].im});
+        cdat2[n] = cmul_dev(w, C{cdat[n].re, cdat[n].im});
     }
     *f0_out = f0;
 }
@@ -216,7 +244,7 @@ inline float scan_position(const C* cdat2, const C* cb42, const uint8_t* mask, u
                 y = cadd(y, cdat2[idx_b]);
             }
         }
-        s = cadd(s, cmul(cconj(y), cb42[idx]));
+        s = cmac_dev(s, cconj(y), cb42[idx]);
     }
     return hypotf(s.re, s.im);
 }
@@ -359,8 +387,8 @@ void softbits_core(const C* cdat2, const C* cb42, const float* pp, const uint8_t
 
     // carrier phase from the 84 sync samples (:88-128)
     C r[42];
-    for(unsigned t = 0; t < 42; t++) r[t] = cmul(c3[t], cconj(cb42[t]));
-    for(unsigned t = 42; t < 84; t++) r[t - 42] = cadd(r[t - 42], cmul(c3[kSecondSyncSample + (t % 42)], cconj(cb42[t % 42])));
+    for(unsigned t = 0; t < 42; t++) r[t] = cmul_dev(c3[t], cconj(cb42[t]));
+    for(unsigned t = 42; t < 84; t++) r[t - 42] = cmac_dev(r[t - 42], c3[kSecondSyncSample + (t % 42)], cconj(cb42[t % 42]));
     for(unsigned t = 0; t < 10; t++) r[t] = cadd(r[t], r[32 + t]);
     for(int size = 16; size > 0; size /= 2)
         for(int t = 0; t < size; t++) r[t] = cadd(r[t], r[t + size]);
@@ -369,7 +397,7 @@ void softbits_core(const C* cdat2, const C* cb42, const float* pp, const uint8_t
     const float phase0 = atan2f(s.im, s.re);  // :137
     const C w = from_phi(phase0);
     const C cfac = cconj(w);
-    for(unsigned n = 0; n < (unsigned)kFrameSamples; n++) c3[n] = cmul(c3[n], cfac);  // :146-153
+    for(unsigned n = 0; n < (unsigned)kFrameSamples; n++) c3[n] = cmul_dev(c3[n], cfac);  // :146-153
 
     // matched filter (:157-180)
     float softbits[kSoftBits];
@@ -384,7 +412,7 @@ void softbits_core(const C* cdat2, const C* cb42, const float* pp, const uint8_t
         {
             const int k = (base1 + d + idx) % kFrameSamples;
             const float v = iq_selection ? c3[k].re : c3[k].im;
-            sb = sb + v * pp[idx];
+            sb = mac_dev(sb, v, pp[idx]);
         }
         softbits[pos_iq * 2 + iq_selection] = sb;
     }
@@ -542,6 +570,11 @@ void fft_radix2(std::vector<C>& a, int sign)
 // =============================================================================================
 extern "C" {
 
+const char* orc_build_variant(void)
+{
+    return kBuildVariant;
+}
+
 int orc_sizeof_item(void)
 {
     return static_cast<int>(sizeof(orc_item));
@@ -626,7 +659,7 @@ void orc_analytic2(const orc_complex* in, orc_complex* out, int with_shift)
     for(int n = 0; n < kWindowSamples; n++) c[kFirPad + n] = {in[n].re, in[n].im};  // :93-115
 
     if(with_shift)
-        for(int i = 0; i < kFirBuffer; i++) c[i] = cmul(c[i], w_left[i & 7]);  // :44-48
+        for(int i = 0; i < kFirBuffer; i++) c[i] = cmul_dev(c[i], w_left[i & 7]);  // :44-48
 
     const int n_filtered = kFirBuffer - 32;  // (NumSlices-1)*32 = 5216 outputs per pass
     // forward pass (:163-187)
@@ -635,7 +668,7 @@ void orc_analytic2(const orc_complex* in, orc_complex* out, int with_shift)
         for(int i = 0; i < n_filtered; i++)
         {
             C s = {0.0f, 0.0f};
-            for(int t = 0; t < kFirTaps; t++) s = cadd(s, smul(kFirTapValue[t], c[i + (16 - kFirTapIndex[t])]));
+            for(int t = 0; t < kFirTaps; t++) s = smac_dev(s, kFirTapValue[t], c[i + (16 - kFirTapIndex[t])]);
             y[i] = s;
         }
         c.swap(y);
@@ -646,13 +679,13 @@ void orc_analytic2(const orc_complex* in, orc_complex* out, int with_shift)
         for(int i = kFirBuffer - 1; i >= kFirBuffer - n_filtered; i--)
         {
             C s = {0.0f, 0.0f};
-            for(int t = 0; t < kFirTaps; t++) s = cadd(s, smul(kFirTapValue[t], c[i - (16 - kFirTapIndex[t])]));
+            for(int t = 0; t < kFirTaps; t++) s = smac_dev(s, kFirTapValue[t], c[i - (16 - kFirTapIndex[t])]);
             z[i] = s;
         }
         c.swap(z);
     }
     if(with_shift)
-        for(int i = 0; i < kFirBuffer; i++) c[i] = cmul(c[i], w_right[i & 7]);  // :85-89
+        for(int i = 0; i < kFirBuffer; i++) c[i] = cmul_dev(c[i], w_right[i & 7]);  // :85-89
 
     for(int n = 0; n < kWindowSamples; n++) out[n] = {c[kFirPad + n].re, c[kFirPad + n].im};  // :224-233
 }

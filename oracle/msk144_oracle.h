@@ -59,6 +59,9 @@ typedef struct orc_ctx
     int num_threads;         /* OpenMP threads used over frequency hypotheses (>=1) */
 } orc_ctx;
 
+/* which build of this file the library is: "parity" (-ffp-contract=off, what the parity tests compare with), "contract-fast" or
+ * "forced-fma" (the two FMA-contracting builds of tests/test_oracle_fma_bracket.py; see the note in msk144_oracle.cpp) */
+const char* orc_build_variant(void);
 int orc_sizeof_item(void);
 void orc_ctx_init(orc_ctx* ctx, float center_freq, float search_width, float search_step, int scan_depth, int nbadsync_threshold);
 void orc_set_threads(orc_ctx* ctx, int n);

@@ -136,6 +136,31 @@ def bench_lib():
     return _load(build_bench_library())
 
 
+_FMA_DIR = os.path.join(_DIR, "_fma")
+FMA_VARIANTS = {"contract-fast": "libmsk144_oracle_contract.so", "forced-fma": "libmsk144_oracle_fmaf.so"}
+
+
+def host_has_fma() -> bool:
+    try:
+        return any(" fma " in line + " " for line in open("/proc/cpuinfo") if line.startswith("flags"))
+    except OSError:
+        return False
+
+
+def fma_lib(variant: str):
+    """One of the two FMA-contracting builds of the oracle source (oracle/Makefile target `fma`; tests/test_oracle_fma_bracket.py)."""
+    subprocess.run(["make", "-s", "-C", _DIR, "fma"], check=True, stdout=subprocess.DEVNULL)
+    L = _load(os.path.join(_FMA_DIR, FMA_VARIANTS[variant]))
+    assert build_variant(L) == variant
+    return L
+
+
+def build_variant(L=None) -> str:
+    L = lib() if L is None else L
+    L.orc_build_variant.restype = C.c_char_p
+    return L.orc_build_variant().decode()
+
+
 def _p(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -30,8 +30,9 @@ EXE = os.environ.get("MSK144_DECODER_EXE") or os.path.join(ROOT, "msk144cudecode
 DEEP = ["--search-width=500", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=3"]
 
 
-def make_streams(n_streams: int, n_hops: int, seed: int = 7):
-    """int16 [n_streams][5184 + n_hops*2592]: AWGN sigma = 1000 LSB; every 4th stream carries one 0 dB ping (bench.py's recipe)."""
+def make_streams(n_streams: int, n_hops: int, seed: int = 7, meta: dict = None):
+    """int16 [n_streams][5184 + n_hops*2592]: AWGN sigma = 1000 LSB; every 4th stream carries one 0 dB ping (bench.py's recipe).
+    `meta`, when given, receives {stream: (first sample, frames) of its ping}."""
     from msk144cudecoder_amd import synth
     n = 5184 + n_hops * 2592
     rng = np.random.default_rng(seed)
@@ -47,6 +48,8 @@ def make_streams(n_streams: int, n_hops: int, seed: int = 7):
         t = np.arange(start, start + frames * 864)
         x[c, start:start + frames * 864] += (amp * np.real(np.tile(bb, frames) * np.exp(1j * (2 * np.pi * freq * t / 12000.0 + rng.uniform(0, 6.28))))).astype(np.float32)
         sent[c] = "".join(str(int(b)) for b in msg)
+        if meta is not None:
+            meta[c] = (start, frames)
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16), sent
 
 
@@ -63,7 +66,7 @@ def parse_timing(err: str):
 
 
 def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = None, timeout_s: float = 180.0, devices: str = None,
-        phase_spread_ms: float = 0.0):
+        phase_spread_ms: float = 0.0, keep_lines=()):
     """devices: value for --devices (e.g. "0,0" or "0,1,2,3"): one ingest+post thread pair per entry, per-device rows in the result.
     phase_spread_ms: every feeder thread's hop clock is offset by a fixed random phase in [0, phase_spread_ms) - streams that are NOT
     phase-aligned (real receivers are not), instead of all hops falling due together."""
@@ -176,6 +179,14 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
     decoded = {}
     for ch, bits in re.findall(r"ch=(\d+); .*?bits='([01]{77})'", out):
         decoded.setdefault(int(ch), set()).add(bits)
+    res["decoded_streams"] = sorted(c for c, b in sent.items() if b in decoded.get(c, set()))
+    if keep_lines:
+        keep = set(int(c) for c in keep_lines)
+        res["lines_by_stream"] = {c: [] for c in keep}
+        for line in out.split("\n"):
+            m = re.match(r"^\*\*\*  ch=(\d+); (.*)$", line)
+            if m and int(m.group(1)) in keep:
+                res["lines_by_stream"][int(m.group(1))].append("***  " + m.group(2))
     res["streams_with_ping"] = len(sent)
     res["pings_decoded"] = sum(1 for c, b in sent.items() if b in decoded.get(c, set()))
     res["warnings"] = err.count("Warning: Working loop takes too much time")
