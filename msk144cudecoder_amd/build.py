@@ -45,28 +45,38 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, out: str = None, defines=(), extra_sources=()) -> str:
+    """The product library.  `out` / `defines` / `extra_sources`: a differently configured copy under its own name and object
+    directory (tools/phase_stamps.py builds the -DMSK144_PHASE_STAMPS diagnostic library this way); the product build takes none."""
     hipcc = _hipcc()
-    os.makedirs(_BUILD, exist_ok=True)
+    lib_path = out or LIB_PATH
+    build_dir = _BUILD if out is None else os.path.join(_BUILD, "variant_" + os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(build_dir, exist_ok=True)
     hdrs = [os.path.join(_CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    flags = ["-D" + d for d in defines]
     objs = []
     relink = force
-    for src, extra in SOURCES:
+    for src, extra in list(SOURCES) + [(s, []) for s in extra_sources]:
         s = os.path.join(_CSRC, src)
-        o = os.path.join(_BUILD, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(build_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + flags + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
             relink = True
-    if relink or _newer(LIB_PATH, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+    if relink or _newer(lib_path, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
+
+
+def build_stamps_library(verbose: bool = False) -> str:
+    """libmsk144hip_stamps.so: the same sources with -DMSK144_PHASE_STAMPS (csrc/phase_stamps.h) - diagnostic only."""
+    return build_library(verbose=verbose, out=os.path.join(_PKG, "libmsk144hip_stamps.so"), defines=["MSK144_PHASE_STAMPS"], extra_sources=["phase_stamps.hip"])
 
 
 if __name__ == "__main__":

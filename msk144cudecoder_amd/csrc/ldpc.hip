@@ -327,10 +327,25 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_kernel(const DeviceStore st
             // LDS cycles each against 4.25 for ds_write_b32, tools/ubench/lds_exec_groups.hip) and never conflict
             {
                 float th[2][kEdgesPerBit];
+                if(iter == 0)
+                {
+                    // first update: every check -> bit message is still 0, so the three edges of a bit all carry toc = zn = llr
+                    // (ldpc_kernel.cuh:225-229 with tov = 0): one tanh per bit instead of three (zn - 0 is exact, same values)
 #pragma unroll
-                for(int h = 0; h < 2; h++)
+                    for(int h = 0; h < 2; h++)
+                    {
+                        const float t0 = tanh_neg_half_scaled(zn[h]);
 #pragma unroll
-                    for(int k = 0; k < kEdgesPerBit; k++) th[h][k] = tanh_neg_half_scaled(zn[h] - tov[h][k]);
+                        for(int k = 0; k < kEdgesPerBit; k++) th[h][k] = t0;
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for(int h = 0; h < 2; h++)
+#pragma unroll
+                        for(int k = 0; k < kEdgesPerBit; k++) th[h][k] = tanh_neg_half_scaled(zn[h] - tov[h][k]);
+                }
                 static_assert(kEdgesPerBit == 3, "six forward stores below");
                 asm volatile("s_mov_b32 m0, %6\n\t"
                              "s_nop 0\n\t"  // SALU write of M0 -> LDS add-TID instruction: one wait state

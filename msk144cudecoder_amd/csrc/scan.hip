@@ -31,6 +31,7 @@
 //     three DPP min steps + ballot (lowest slot wins ties), conditional replace.
 #include "msk144_kernels.h"
 #include "mix.h"
+#include "phase_stamps.h"
 #include "wave64.h"
 
 #include <utility>
@@ -64,6 +65,7 @@ struct ScanArgs
     float pp[12];
     int total_tiles;
     int tiles_per_xcd;
+    MSK144_STAMP_ARG
 };
 
 // LDS pointer kept volatile so that the 50 sample loads stay ds_read_b64 (2 LDS cycles each); merged into
@@ -191,6 +193,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    MSK144_STAMP_ROW(tile);
+    MSK144_STAMP(0);
+    MSK144_STAMP(11);  // two stamps back to back: the stamp's own cost
 
     // ---- 1. mix down by the hypothesis frequency (scan_kernel.cuh:45-69) ----
     const float f0 = -1.0f * a.st.freq[b];
@@ -211,7 +216,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
             if(n < kWrapPad) s_buf[kWindowSamples + n] = y;
         }
     }
+    MSK144_STAMP(1);
     __syncthreads();
+    MSK144_STAMP(2);
 
     // ---- 2. C[n0 + 6r], r = 0..10, by pulse decomposition (correlate_pulses); C then overwrites the window in place ----
     {
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         const int n0 = kOutSpan * q + (tid - u * kPulseHalf);
         float2 c[kOutPerThread];
         if(q < kOutGroups) correlate_pulses((lds_f2_ptr)(s_buf + n0), a.pp, c);
+        MSK144_STAMP(3);
         __syncthreads();  // every thread has read its samples: C may overwrite the window
         if(q < kOutGroups)
         {
@@ -238,6 +246,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         }
     }
     __syncthreads();
+    MSK144_STAMP(4);
 
     // ---- 2b. E[n] = C[n] + C[n + 336 mod N]: the two sync words of a frame, summed once per ring position ----
     // S(pos, p) = sum over the pattern's frames of E[(pos + 864 m) mod N]: the fold then needs one load and one complex add per
@@ -269,6 +278,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         }
     }
     __syncthreads();
+    MSK144_STAMP(5);
 
     // ---- 3. fold per pattern, |S|^2, running arg-max along this lane's run of positions ----
     // kD is a template parameter: the pattern loop is straight-line code.  Patterns 7 and 8 (100100, 100110) reuse the frames
@@ -351,6 +361,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for(int p = 0; p < D; p++) bidx[p] += start;
     }
+    MSK144_STAMP(6);
     // ---- 3b. the 24 runs of a slice meet: octet maxima in registers, three octets per slice through LDS ----
     // Runs sit in lane order (tid = 24 slice + run), so a slice is exactly three aligned groups of eight lanes.  Each octet reduces
     // its eight running maxima with three DPP steps and the FIRST lane holding the maximum (lowest position: the reference's
@@ -379,7 +390,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
             }
         }
     }
+    MSK144_STAMP(7);
     __syncthreads();
+    MSK144_STAMP(8);
 
     // ---- 4a. slice maximum = first strict maximum over its three octets in position order, xb = |S| (correctly rounded sqrt) ----
     for(int e = tid; e < D * kScanSlices; e += kScanThreads)
@@ -403,6 +416,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
         s_xpos[p][sl] = bp;
     }
     __syncthreads();
+    MSK144_STAMP(9);
+    if(wave != 0) MSK144_STAMP_WAVE_END();
 
     // ---- 4b. 8-slot replacement rule in slice order (scan_kernel.cuh:276-353), one wave: lane = 8*pattern + slot ----
     if(wave == 0)
@@ -446,6 +461,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
             a.st.pos[base + slot] = my_pos;
             a.st.xb[base + slot] = my_xb;
         }
+        MSK144_STAMP(10);
+        MSK144_STAMP_WAVE_END();
     }
 }
 
@@ -458,6 +475,9 @@ void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t str
     for(int i = 0; i < 12; i++) a.pp[i] = tpl.pp[i];
     a.total_tiles = st.channels * st.F;
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
+#ifdef MSK144_PHASE_STAMPS
+    a.stamps = stamp_buffer(0);
+#endif
     const dim3 grid(a.tiles_per_xcd * 8), block(kScanThreads);
     switch(st.D)
     {

@@ -26,6 +26,7 @@
 // 42->32->16 tree: ~1e-7 relative on a rotation angle).
 #include "msk144_kernels.h"
 #include "mix.h"
+#include "phase_stamps.h"
 #include "wave64.h"
 
 namespace msk144
@@ -50,6 +51,7 @@ struct SoftbitsArgs
     SyncTemplate tpl;
     int total_tiles;
     int tiles_per_xcd;
+    MSK144_STAMP_ARG
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -76,7 +78,11 @@ typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
 template<int kSlotMask>
 __device__ __forceinline__ void fold_frames(v2f (&acc)[kSlots][kGroup], const char* xbytes, const uint32_t (&lane8)[kSlots], uint32_t pos, int p)
 {
+#ifdef MSK144_LISTING_EVEN_ONLY
+    const bool pos_even = true;  // tools/phase_stamps.py prices ONE of the two alignment paths of a listing (never a run build)
+#else
     const bool pos_even = (pos & 1u) == 0u;
+#endif
     if(pos_even)
     {
 #pragma unroll
@@ -195,6 +201,9 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MSK144_STAMP_ROW(tile);
+    MSK144_STAMP(0);
+    MSK144_STAMP(11);  // two stamps back to back: the stamp's own cost
 
     // Candidates of this wave: c = wave + 8 i, i < D.  Their scan positions are fetched once, lane i holding candidate i's
     // (the latency hides under the mix phase), and handed out by readlane: the position is a scalar in the candidate loop.
@@ -229,7 +238,12 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
             }
         }
     }
+    MSK144_STAMP(1);
     __syncthreads();
+    MSK144_STAMP(2);
+#ifdef MSK144_PHASE_STAMPS
+    uint64_t st_part1 = 0, st_part2 = 0, st_n2 = 0;  // wave 0: cycles in part one / part two of its candidates, part-two runs
+#endif
 
     // Phase estimate = sum over the two sync words of folded sample x conj(template) (softbits_kernel.cuh:88-137).  The first
     // sync word covers samples 0..41 = groups 0..6 (lanes 0..6 of slot 0), the second samples 336..377 = groups 56..62.
@@ -290,6 +304,9 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const size_t item = item0 + c;
         uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), i));
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
+#ifdef MSK144_PHASE_STAMPS
+        const uint64_t st_t0 = (stamp_row_ && tid < 64) ? stamp_now() : 0;
+#endif
 
         // ---- part 1: everything the sync check needs.  The sync softbits 0..7 and 56..63 live in slot 0; softbit 0 also takes
         // the partial sum that starts in group 143 (slot 2, lane 15): the frame is circular.  Slot 1 waits. ----
@@ -346,6 +363,10 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const bool disagree = sync_pm != 0 && hard != sync_pm;
         const int nbad = __popcll(__ballot(disagree));
         if(lane == 0) a.st.nbadsync[item] = nbad;
+#ifdef MSK144_PHASE_STAMPS
+        const uint64_t st_t1 = (stamp_row_ && tid < 64) ? stamp_now() : 0;
+        st_part1 += st_t1 - st_t0;
+#endif
         if(kGateEarly && nbad > a.st.nbadsync_threshold) continue;  // wave-uniform: the index stage drops this candidate
 
         // ---- part 2: the middle slot and the rest of the demodulation ----
@@ -392,7 +413,24 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         if(lane >= 8 && lane < 56) llr[lane - 8] = f32_mul(scale, soft[0]);      // u = 8..55    -> 0..47
         llr[48 + lane] = f32_mul(scale, soft[1]);                                // u = 64..127  -> 48..111
         if(lane < 16) llr[112 + lane] = f32_mul(scale, soft[2]);                 // u = 128..143 -> 112..127
+#ifdef MSK144_PHASE_STAMPS
+        if(stamp_row_ && tid < 64)
+        {
+            st_part2 += stamp_now() - st_t1;
+            st_n2++;
+        }
+#endif
     }
+#ifdef MSK144_PHASE_STAMPS
+    if(stamp_row_ && tid == 0)
+    {
+        stamp_row_[3] = st_part1;
+        stamp_row_[4] = st_part2;
+        stamp_row_[5] = st_n2;
+    }
+#endif
+    MSK144_STAMP(6);
+    MSK144_STAMP_WAVE_END();
 }
 
 }  // namespace
@@ -404,6 +442,9 @@ void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t
     a.tpl = tpl;
     a.total_tiles = st.nch * st.F;
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
+#ifdef MSK144_PHASE_STAMPS
+    a.stamps = stamp_buffer(1);
+#endif
     const int grid = a.tiles_per_xcd * 8;
     // LLR rows are retained only when one block covers every channel of the handle (msk144_api.cpp: dumps, parity tests)
     if(st.gate_early) hipLaunchKernelGGL(softbits_kernel<true>, dim3(grid), dim3(kSbThreads), 0, stream, a);

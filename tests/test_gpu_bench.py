@@ -21,8 +21,8 @@ def _bench(extra):
 
 
 def test_launcher_line_matches_the_plain_run():
-    plain = _bench(["--no-cpu-baseline"])
-    dist = _bench(["--gpus", "1", "--launcher", "--no-cpu-baseline"])
+    plain = _bench(["--no-cpu-baseline", "--sustain-seconds", "0"])       # without the sustained leg both runs end on the same window
+    dist = _bench(["--gpus", "1", "--launcher", "--no-cpu-baseline", "--sustain-seconds", "0"])
     assert plain["n_gpus"] == dist["n_gpus"] == 1
     assert plain["config"]["launch"] == "single process" and dist["config"]["launch"] == "torch.distributed.run"
     g = dist["gather"]
@@ -41,3 +41,14 @@ def test_distributed_line_carries_the_cpu_baseline():
     cb = dist["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "-march=native" in cb["flags"]
     assert "gather" in dist and "roofline" in dist
+    assert "timed in the launcher parent" in cb["sample"]
+    # the sustained leg: the same step held for ~10 s; markers on the decode stream must SEE the kernels (a marker on another
+    # stream reads a fraction of the step time), the probe must read a shader clock, and the gather of the leg's last step must
+    # have carried that step's records (bench.py validates it and would have exited non-zero)
+    su = dist["sustained"]
+    assert su["seconds"] >= 8.0 and su["steps"] >= 150
+    for k in ("first50", "mid50", "last50"):
+        assert abs(su["ms_per_step"][k] / dist["ms_per_step"] - 1.0) < 0.10, (k, su["ms_per_step"], dist["ms_per_step"])
+    assert abs(su["drift_last_vs_first"]) < 0.05
+    assert all(1200.0 < su["clock_mhz"][k] < 2700.0 for k in ("first", "mid", "last")), su["clock_mhz"]
+    assert dist["gather"]["records_last_step"] == dist["decodes_last_step"]
