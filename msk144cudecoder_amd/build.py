@@ -45,9 +45,12 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = False, out: str = None, defines=(), extra_sources=()) -> str:
-    """The product library.  `out` / `defines` / `extra_sources`: a differently configured copy under its own name and object
-    directory (tools/phase_stamps.py builds the -DMSK144_PHASE_STAMPS diagnostic library this way); the product build takes none."""
+def build_library(force: bool = False, verbose: bool = False, out: str = None, defines=(), extra_sources=(), overrides=None) -> str:
+    """The product library.  `out` / `defines` / `extra_sources` / `overrides`: a differently configured copy under its own name and
+    object directory (tools/phase_stamps.py builds the -DMSK144_PHASE_STAMPS diagnostic library this way; tools/ab_build.py swaps
+    single sources for an earlier revision's, {"ldpc.hip": "/path/to/old/ldpc.hip"}, for same-box A/B runs); the product build
+    takes none."""
+    overrides = overrides or {}
     hipcc = _hipcc()
     lib_path = out or LIB_PATH
     build_dir = _BUILD if out is None else os.path.join(_BUILD, "variant_" + os.path.splitext(os.path.basename(out))[0])
@@ -57,11 +60,11 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, d
     objs = []
     relink = force
     for src, extra in list(SOURCES) + [(s, []) for s in extra_sources]:
-        s = os.path.join(_CSRC, src)
+        s = overrides.get(src, os.path.join(_CSRC, src))
         o = os.path.join(build_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            cmd = [hipcc] + COMMON + flags + extra + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + flags + extra + ["-I", _CSRC, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -193,6 +193,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+#ifdef MSK144_EXP_PRIO
+    __builtin_amdgcn_s_setprio(3);  // experiment: the latency-bound start of a workgroup (global loads, mix) ahead of the older, VALU-bound waves
+#endif
     MSK144_STAMP_ROW(tile);
     MSK144_STAMP(0);
     MSK144_STAMP(11);  // two stamps back to back: the stamp's own cost
@@ -218,6 +221,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     }
     MSK144_STAMP(1);
     __syncthreads();
+#ifdef MSK144_EXP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     MSK144_STAMP(2);
 
     // ---- 2. C[n0 + 6r], r = 0..10, by pulse decomposition (correlate_pulses); C then overwrites the window in place ----
@@ -381,7 +387,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for(int p = 0; p < D; p++)
         {
-            const bool is_max = best[p] == omax[p];
+            // >= rather than ==: omax is the DPP maximum of the octet's own values, so the two are the same test - unless the
+            // maximum did not survive v_max_f32_dpp bit for bit (a build that flushes denormals would turn a denormal |S|^2 into 0):
+            // then every lane at or above the flushed value qualifies and the first of them stores, instead of none (the slice
+            // merge below would read an unwritten cell).  tests/test_gpu_parity.py::test_scan_tiny_amplitude_window feeds denormal |S|^2.
+            const bool is_max = best[p] >= omax[p];
             const uint64_t eq = __ballot(is_max);
             if(is_max && (eq & lower) == 0ull)
             {
@@ -422,6 +432,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     // ---- 4b. 8-slot replacement rule in slice order (scan_kernel.cuh:276-353), one wave: lane = 8*pattern + slot ----
     if(wave == 0)
     {
+#ifdef MSK144_EXP_TAILPRIO
+        __builtin_amdgcn_s_setprio(3);  // experiment: the one-wave tail that keeps the workgroup's LDS ahead of everything else on its SIMD
+#endif
         const int p = lane >> 3;
         const int slot = lane & 7;
         const int pc = p < D ? p : 0;  // lanes of unused patterns shadow pattern 0 and store nothing

@@ -73,6 +73,28 @@ def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_me
     return out
 
 
+def printed_payloads(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, threads: int = 8) -> set:
+    """The 77-bit payloads `msk144hipdecoder --print-bits` would print for `stream`: accepted payloads whose own text (decoded with
+    a fresh hash table, as the program does for that option) is the text of an output line.  A payload the text layer rejects is
+    accepted by the decoder but never printed."""
+    acc = set()
+    lines = decode_stream(stream, cfg, read_mode, analytic_method, threads=threads, payloads=acc)
+    texts = set(re.findall(r"msg='(.*)'; $", "\n".join(lines), flags=re.M))
+    H = C.CDLL(HOST_SO)
+    H.msk144host_table_new.restype = C.c_void_p
+    H.msk144host_table_free.argtypes = [C.c_void_p]
+    H.msk144host_decode_message.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    out = set()
+    for bits in acc:
+        table = H.msk144host_table_new()
+        buf = C.create_string_buffer(64)
+        ok = H.msk144host_decode_message(table, bytes(int(b) for b in bits), buf)
+        H.msk144host_table_free(table)
+        if ok and buf.value.decode() in texts:
+            out.add(bits)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--center-frequency", type=float, default=None)

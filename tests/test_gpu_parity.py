@@ -331,3 +331,24 @@ def test_result_overflow_is_reported(hip):
         assert rc == -5 and got.value == n                      # MSK144_EOVERFLOW, exact count
         assert (out["item"][:4] > 0).all() and (out["item"][4:] == 0).all()
         assert np.all(np.diff(out["item"][:4]) > 0)
+
+
+def test_scan_tiny_amplitude_window(orc, hip, parity_report):
+    """ADVICE r3 (scan.hip octet merge): an analytic window scaled until |S|^2 is a DENORMAL float for the noise positions.  The
+    kernels are built with denormals preserved (hipcc default, no -fgpu-flush-denormals-to-zero): the octet maxima survive the DPP
+    max bit for bit, every slot is written, and the scan agrees with the oracle as on a full-scale window.  (A flushing build would
+    have left s_oct cells unwritten with the former == test; the >= test stores in that case too.)"""
+    cfg = dict(center=1500.0, width=8.0, step=1.0, depth=6, nbadsync_threshold=2)
+    x, _ = _audio_window(41, snr=3.0, n_frames=4, freq=1501.0)
+    o = orc.Oracle(threads=8, **cfg)
+    cd = (o.frontend_audio(x, 2) * np.float32(2e-21)).astype(np.complex64)      # rms 2e-21: |S|^2 of noise positions ~1e-40
+    items_o = o.scan(cd)
+    assert float(np.min(items_o["xb"].astype(np.float64) ** 2)) < 1.17e-38     # denormal |S|^2 among the stored maxima
+    with hip.HipDecoder(channels=1, **cfg) as d:
+        d.submit_analytic(cd)
+        d.decode(hip.STAGE_SCAN)
+        items_g = d.dump_candidates(0)
+    assert np.all(items_g["xb"] > 0) and np.all(np.isfinite(items_g["xb"]))
+    rep = parity.compare_scan(o, cd, items_o, items_g)
+    assert rep["near_ties"] <= max(4, rep["total"] // 50), rep                  # denormals carry fewer bits: a few more verified near-ties
+    parity_report("scan_tiny_amplitude", rep)

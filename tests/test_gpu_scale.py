@@ -18,24 +18,19 @@ LINE_SAMPLE = (0, 1, 2, 4)            # two streams with a ping (0, 4), two with
 RATE_SAMPLE = tuple(range(0, 96, 4))  # 24 streams with a ping: decoded or not, stream by stream, against the oracle
 
 
-def _oracle_decodes_ping(orc, o, stream, start, frames, bits):
-    """Does the oracle accept the stream's transmitted payload in any window that overlaps its ping?"""
+def _oracle_prints_ping(oracle_cli, stream, start, frames, bits):
+    """Would the oracle-driven decoder print the stream's transmitted payload?  Only the windows that overlap the ping can hold it."""
     n_win = (len(stream) - 5184) // 2592 + 1
-    for w in range(n_win):
-        a = w * 2592
-        if a + 5184 <= start or a >= start + frames * 864:
-            continue
-        items, _ = o.decode_window(o.frontend_audio(stream[a:a + 5184], 2))
-        for it in items[items["is_message_present"] == 1]:
-            if "".join(str(int(b)) for b in it["message"]) == bits:
-                return True
-    return False
+    hit = [w for w in range(n_win) if not (w * 2592 + 5184 <= start or w * 2592 >= start + frames * 864)]
+    sub = stream[hit[0] * 2592: hit[-1] * 2592 + 5184]
+    return bits in oracle_cli.printed_payloads(sub, DEEP_CFG, 1, 2, threads=16)
 
 
 def test_1024_realtime_streams_deep_config_no_late_hops(orc, parity_report):
     import host_scale
     from oracle import oracle_cli
     res = host_scale.run(1024, 20, pace_ms=216.0, keep_lines=LINE_SAMPLE)
+    assert LINE_SAMPLE and RATE_SAMPLE
     assert res["returncode"] == 0 and res["feeder_errors"] == 0, res
     assert res["stream_hops"] == 1024 * 21                      # nothing dropped
     assert res["late_hops"] == 0 and res["worst_latency_ms"] <= 210, res
@@ -55,8 +50,7 @@ def test_1024_realtime_streams_deep_config_no_late_hops(orc, parity_report):
         printed = set(re.findall(r"bits='([01]{77})'", "\n".join(res["lines_by_stream"][c])))
         assert printed <= accepted and ((c in res["decoded_streams"]) == (c in sent and sent[c] in printed))
     # 2. decoded-or-not for 24 pinged streams, stream by stream: the program's verdict is the oracle's
-    o = orc.Oracle(threads=16, **DEEP_CFG)
-    oracle_says = {c: _oracle_decodes_ping(orc, o, streams[c], meta[c][0], meta[c][1], sent[c]) for c in RATE_SAMPLE}
+    oracle_says = {c: _oracle_prints_ping(oracle_cli, streams[c], meta[c][0], meta[c][1], sent[c]) for c in RATE_SAMPLE}
     program_says = {c: c in res["decoded_streams"] for c in RATE_SAMPLE}
     assert program_says == oracle_says
     # 3. the overall decode rate is bounded by the oracle's rate on that sample (not by a hand-picked constant): 0 dB pings of 3-6

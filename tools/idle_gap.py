@@ -93,11 +93,24 @@ def main():
             step(k)
             return probes(n_probe)
 
+        import threading
+
+        def idle_sleeper(k):
+            # one wave asleep on one CU for the whole pause (the clock probe's own kernel, s_sleep + a 100 MHz counter read per round):
+            # does a BUSY queue hold the clock, or does the governor look at activity?
+            th = threading.Thread(target=lambda: [d.clock_probe(85000) for _ in range(max(1, int(a.idle_ms // 85)))])
+            th.start()
+            time.sleep(a.idle_ms * 1e-3)
+            th.join()
+            step(k)
+            return probes(n_probe)
+
         record("b2b", b2b)
         record("idle", idle)
         record("b2b_again", b2b)
         record("idle+warm", idle_warm)
-        for ms in (20.0, 50.0, 100.0, 400.0):
+        record("idle+sleeper", idle_sleeper)
+        for ms in (1.0, 2.0, 5.0, 10.0, 20.0, 50.0, 100.0, 400.0):
             a.idle_ms = ms
             record(f"idle_{int(ms)}ms", idle)
     if a.out:
