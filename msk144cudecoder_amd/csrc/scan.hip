@@ -193,9 +193,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-#ifdef MSK144_EXP_PRIO
-    __builtin_amdgcn_s_setprio(3);  // experiment: the latency-bound start of a workgroup (global loads, mix) ahead of the older, VALU-bound waves
-#endif
     MSK144_STAMP_ROW(tile);
     MSK144_STAMP(0);
     MSK144_STAMP(11);  // two stamps back to back: the stamp's own cost
@@ -221,9 +218,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     }
     MSK144_STAMP(1);
     __syncthreads();
-#ifdef MSK144_EXP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     MSK144_STAMP(2);
 
     // ---- 2. C[n0 + 6r], r = 0..10, by pulse decomposition (correlate_pulses); C then overwrites the window in place ----
@@ -432,9 +426,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     // ---- 4b. 8-slot replacement rule in slice order (scan_kernel.cuh:276-353), one wave: lane = 8*pattern + slot ----
     if(wave == 0)
     {
-#ifdef MSK144_EXP_TAILPRIO
-        __builtin_amdgcn_s_setprio(3);  // experiment: the one-wave tail that keeps the workgroup's LDS ahead of everything else on its SIMD
-#endif
         const int p = lane >> 3;
         const int slot = lane & 7;
         const int pc = p < D ? p : 0;  // lanes of unused patterns shadow pattern 0 and store nothing

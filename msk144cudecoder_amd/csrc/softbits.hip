@@ -190,7 +190,6 @@ template<bool kGateEarly>
 __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsArgs a)
 {
     __shared__ __attribute__((aligned(16))) float2 s_x[kWindowSamples + kRingPad + 3];
-    __shared__ uint32_t s_next;  // next unclaimed candidate of this tile (work queue of the eight waves)
 
     const int xcd = blockIdx.x & 7;
     const int tile = xcd * a.tiles_per_xcd + (blockIdx.x >> 3);
@@ -202,26 +201,17 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef MSK144_EXP_PRIO
-    __builtin_amdgcn_s_setprio(3);  // experiment: the latency-bound start of a workgroup (global loads, mix) ahead of the older, VALU-bound waves
-#endif
     MSK144_STAMP_ROW(tile);
     MSK144_STAMP(0);
     MSK144_STAMP(11);  // two stamps back to back: the stamp's own cost
 
-    // The D*8 candidates of the tile are a QUEUE the eight waves draw from, longest first (k-th draw = candidate ncand-1-k: the
-    // patterns that average most frames cost most).  A fixed share (candidate w + 8 i for wave w) left the waves of a workgroup
-    // ending up to 5.5 k cycles apart - the nbadsync gate stops a random third of the candidates after part one - while the
-    // workgroup's 48 KB of LDS stay taken until the last one ends (phase stamps: profiles/r04_phase_cycles.txt).  Every
-    // candidate's result depends on the candidate alone, so the draw order changes nothing that is stored.
-    // The scan positions are fetched once, lane c holding candidate c's (the latency hides under the mix phase), and handed out by
-    // readlane: the position is a scalar in the candidate loop.
+    // Candidates of this wave: c = wave + 8 i, i < D.  Their scan positions are fetched once, lane i holding candidate i's
+    // (the latency hides under the mix phase), and handed out by readlane: the position is a scalar in the candidate loop.
     const int D = a.st.D;
-    const int ncand = D * kSlotsPerPattern;  // <= 64
+    const int ncand = D * kSlotsPerPattern;
     const size_t item0 = static_cast<size_t>(ch) * a.st.K + static_cast<size_t>(b) * ncand;
     uint32_t pos_of_lane = 0u;
-    if(lane < ncand) pos_of_lane = a.st.pos[item0 + lane];
-    if(tid == 0) s_next = kSbWaves;  // draws 0..7 are the waves' first candidates
+    if(lane < D) pos_of_lane = a.st.pos[item0 + wave + kSbWaves * lane];
 
     // ---- mix (softbits_kernel.cuh:27-52) ----
     const float f0 = -1.0f * a.st.freq[b];
@@ -250,9 +240,6 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     }
     MSK144_STAMP(1);
     __syncthreads();
-#ifdef MSK144_EXP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     MSK144_STAMP(2);
 #ifdef MSK144_PHASE_STAMPS
     uint64_t st_part1 = 0, st_part2 = 0, st_n2 = 0;  // wave 0: cycles in part one / part two of its candidates, part-two runs
@@ -310,15 +297,12 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     for(int k = 0; k < 8; k++)
         if(lane == k || lane == kSecondSyncBit + k) sync_pm = kSync8Pm[k];
 
-    for(int k = wave; k < ncand;)
+    for(int i = 0; i < D; i++)
     {
-        const int c = ncand - 1 - k;
+        const int c = wave + kSbWaves * i;
         const int p = c / kSlotsPerPattern;
         const size_t item = item0 + c;
-        uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), c));
-        // claim the next candidate now, read the answer at the end of this one: the LDS atomic's latency hides under the fold
-        uint32_t k_next = 0u;
-        if(lane == 0) k_next = atomicAdd(&s_next, 1u);
+        uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), i));
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
 #ifdef MSK144_PHASE_STAMPS
         const uint64_t st_t0 = (stamp_row_ && tid < 64) ? stamp_now() : 0;
@@ -383,7 +367,6 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const uint64_t st_t1 = (stamp_row_ && tid < 64) ? stamp_now() : 0;
         st_part1 += st_t1 - st_t0;
 #endif
-        k = __builtin_amdgcn_readfirstlane(static_cast<int>(k_next));
         if(kGateEarly && nbad > a.st.nbadsync_threshold) continue;  // wave-uniform: the index stage drops this candidate
 
         // ---- part 2: the middle slot and the rest of the demodulation ----
