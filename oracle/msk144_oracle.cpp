@@ -56,10 +56,61 @@ inline float mac_dev(float s, float a, float b) { return s + a * b; }
 #define ORC_VARIANT_NAME "parity"
 #endif
 const char* const kBuildVariant = ORC_VARIANT_NAME;  // named by the Makefile target that set the flags
+
+// ---- math-library bracket (tests/test_oracle_fma_bracket.py, third build "cuda-libm") ----
+// The reference's device code calls CUDA's sincosf, atan2f, hypotf and tanhf (smath_complex.h:79-85 and abs(), softbits_kernel.cuh:137,
+// ldpc_kernel.cuh:236); this oracle calls glibc's, which are correctly rounded or within 1 ulp.  CUDA documents larger errors (CUDA C
+// Programming Guide, "Mathematical Functions": sincosf 2 ulp, atan2f 3 ulp, hypotf 3 ulp, tanhf 2 ulp; sqrtf and division are correctly
+// rounded by default) and its results are not available here.  With -DORC_PERTURB_ULP the four calls return glibc's value moved by a
+// deterministic pseudo-random number of ulps within those bounds (a hash of the argument bits: the same argument always gives the same
+// result, as a real library would) - not CUDA's values, but values as far from the true ones as CUDA's may be.
+#ifdef ORC_PERTURB_ULP
+inline uint32_t hash_bits(uint32_t a, uint32_t b)
+{
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u + (a << 6) + (a >> 2));
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return h;
+}
+inline float nudge(float v, int max_ulp, uint32_t h)
+{
+    if(!std::isfinite(v) || v == 0.0f) return v;
+    const int k = static_cast<int>(h % static_cast<uint32_t>(2 * max_ulp + 1)) - max_ulp;  // -max_ulp .. +max_ulp
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    u = static_cast<uint32_t>(static_cast<int32_t>(u) + (v > 0.0f ? k : -k));  // k ulps away from zero for k > 0, either sign of v
+    float r;
+    std::memcpy(&r, &u, 4);
+    return std::isfinite(r) ? r : v;
+}
+inline uint32_t fbits(float x)
+{
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return u;
+}
+inline void lib_sincosf(float x, float* s, float* c)
+{
+    sincosf(x, s, c);
+    *s = nudge(*s, 2, hash_bits(fbits(x), 1u));
+    *c = nudge(*c, 2, hash_bits(fbits(x), 2u));
+}
+inline float lib_atan2f(float y, float x) { return nudge(atan2f(y, x), 3, hash_bits(fbits(y), fbits(x))); }
+inline float lib_hypotf(float x, float y) { return nudge(hypotf(x, y), 3, hash_bits(fbits(x), fbits(y) ^ 0x55u)); }
+inline float lib_tanhf(float x) { return nudge(tanhf(x), 2, hash_bits(fbits(x), 3u)); }
+#else
+inline void lib_sincosf(float x, float* s, float* c) { sincosf(x, s, c); }
+inline float lib_atan2f(float y, float x) { return atan2f(y, x); }
+inline float lib_hypotf(float x, float y) { return hypotf(x, y); }
+inline float lib_tanhf(float x) { return tanhf(x); }
+#endif
 inline C from_phi(float phi)                                                                             // :79-85
 {
     float s, c;
-    sincosf(phi, &s, &c);
+    lib_sincosf(phi, &s, &c);
     return {c, s};
 }
 
@@ -246,7 +297,7 @@ inline float scan_position(const C* cdat2, const C* cb42, const uint8_t* mask, u
         }
         s = cmac_dev(s, cconj(y), cb42[idx]);
     }
-    return hypotf(s.re, s.im);
+    return lib_hypotf(s.re, s.im);
 }
 
 struct Slot
@@ -394,7 +445,7 @@ void softbits_core(const C* cdat2, const C* cb42, const float* pp, const uint8_t
         for(int t = 0; t < size; t++) r[t] = cadd(r[t], r[t + size]);
 
     const C s = r[0];
-    const float phase0 = atan2f(s.im, s.re);  // :137
+    const float phase0 = lib_atan2f(s.im, s.re);  // :137
     const C w = from_phi(phase0);
     const C cfac = cconj(w);
     for(unsigned n = 0; n < (unsigned)kFrameSamples; n++) c3[n] = cmul_dev(c3[n], cfac);  // :146-153
@@ -523,7 +574,7 @@ bool ldpc_core(const float* softbits, char* message77, int* iters_out, int* nhar
                 float product = 1.0f;
                 for(int j = 0; j < 11; j++)
                 {
-                    if((j < 10 || mp.full_row[column]) && j != row_to_exclude) product *= tanhf(-0.5f * toc[j][column]);
+                    if((j < 10 || mp.full_row[column]) && j != row_to_exclude) product *= lib_tanhf(-0.5f * toc[j][column]);
                 }
                 tov[k][n] = 2.0f * platanh(-product);
             }

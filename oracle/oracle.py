@@ -137,7 +137,8 @@ def bench_lib():
 
 
 _FMA_DIR = os.path.join(_DIR, "_fma")
-FMA_VARIANTS = {"contract-fast": "libmsk144_oracle_contract.so", "forced-fma": "libmsk144_oracle_fmaf.so"}
+FMA_VARIANTS = {"contract-fast": "libmsk144_oracle_contract.so", "forced-fma": "libmsk144_oracle_fmaf.so",
+                "cuda-libm": "libmsk144_oracle_libm.so", "cuda-like": "libmsk144_oracle_cudalike.so"}
 
 
 def host_has_fma() -> bool:

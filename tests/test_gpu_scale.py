@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 DEEP_CFG = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
-LINE_SAMPLE = (0, 1, 2, 4)            # two streams with a ping (0, 4), two without (1, 2): every line against the oracle-driven decoder
+LINE_SAMPLE = (0, 1, 2, 4, 8, 12)     # four streams with a ping (0, 4, 8, 12), two without (1, 2): every line against the oracle-driven decoder
 RATE_SAMPLE = tuple(range(0, 96, 4))  # 24 streams with a ping: decoded or not, stream by stream, against the oracle
 
 
@@ -37,7 +37,7 @@ def test_1024_realtime_streams_deep_config_no_late_hops(orc, parity_report):
     # ---- what the 1024 streams printed, against the oracle ----
     meta = {}
     streams, sent = host_scale.make_streams(1024, 20, meta=meta)            # the harness's own seeded streams, regenerated
-    # 1. four streams, all 21 windows each: every output line (snr, f0, num_avg, nbadsync, pattern, text) is the oracle-driven
+    # 1. six streams, all 21 windows each: every output line (snr, f0, num_avg, nbadsync, pattern, text) is the oracle-driven
     #    CPU decoder's, in order; the 77 printed bits of the pinged streams are the transmitted payload
     for c in LINE_SAMPLE:
         got = [re.sub(r"' bits='[01]{77}", "", re.sub(r"date=\d{14}", "date=X", l)) for l in res["lines_by_stream"][c]]

@@ -2,9 +2,11 @@
 
 The parity build of the oracle contracts nothing (-ffp-contract=off); the reference's CUDA binary contracts a*b+c into FMAs in
 device code (nvcc default, CMakeLists.txt:130-132), and cannot be built here.  Two further builds of the SAME oracle
-source bracket what that binary may compute (oracle/Makefile target `fma`, note at the top of oracle/msk144_oracle.cpp):
-"contract-fast" (gcc -ffp-contract=fast -mfma, everything fusable fused) and "forced-fma" (complex products and the three
-accumulate hot spots as fully fused chains).  Over the golden corpus, >= 200 fuzz configurations and one deep window this test
+source bracket what that binary may compute (oracle/Makefile target `fma`, notes at the top of oracle/msk144_oracle.cpp):
+"contract-fast" (gcc -ffp-contract=fast -mfma, everything fusable fused), "forced-fma" (complex products and the three
+accumulate hot spots as fully fused chains), "cuda-libm" (glibc's sincosf / atan2f / hypotf / tanhf moved by deterministic
+pseudo-random ulps within CUDA's documented error bounds: 2 / 3 / 3 / 2) and "cuda-like" (forced FMAs and moved math library
+together).  Over the golden corpus, >= 200 fuzz configurations and one deep window this test
 asserts, for each contracting build against the parity build on the same raw input:
 
   * payload sets identical, index lists identical wherever nbadsync is, accept / iteration identical,
@@ -30,7 +32,7 @@ for p in (ROOT, HERE):
 import parity  # noqa: E402
 from test_gpu_fuzz import _case  # noqa: E402  (the seeded configuration / window generator of the GPU fuzz sweep)
 
-VARIANTS = ("contract-fast", "forced-fma")
+VARIANTS = ("contract-fast", "forced-fma", "cuda-libm", "cuda-like")
 
 
 def _frontend(o, x, read_mode, method):
@@ -125,7 +127,9 @@ def test_decisions_survive_fma_contraction(orc, variant):
     print(variant, json.dumps({k: v for k, v in tally.items() if k != "payload_set_cases"}))
     assert tally["windows"] >= n                                   # (the all-zero golden window returns early)
     assert tally["payload_sets_changed"] == 0, tally["payload_set_cases"]
-    assert tally["frontend_samples_changed"] > 0                   # the bracket is not vacuous: contraction does move the reals
+    # the bracket is not vacuous: contraction moves the front end's samples, the math-library builds (no transcendental in the FIR
+    # front end) move the LLRs
+    assert tally["frontend_samples_changed"] > 0 or tally["llr_max_abs_diff"] > 0.0
     # every moved decision was verified as a near-tie inside compare_*; their share must stay what "rounding-level" means
     assert tally["scan_near_ties"] <= 1e-3 * tally["slots"] and tally["bp_marginal_flips"] <= 1e-3 * max(tally["bp_compared"], 1)
     # a group's gate count may move only with a verified near-tie or a verified marginal sync softbit
