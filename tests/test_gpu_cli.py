@@ -165,6 +165,15 @@ def test_cli_interleaved_equals_single_streams():
     for c in range(3):
         assert per_ch[c] == singles[c], c
     assert "(interleaved on stdin)" in err
+    # the same stdin split over two device loops (streams 0..1 | 2), one reader handing every loop its slice of each block
+    rc, out, err = _run(args + ["--interleaved=3", "--devices=0,0"], b"".join(blocks))
+    assert rc == 0, err
+    split = {c: [] for c in range(3)}
+    for l in out.strip().split("\n")[:-1]:
+        m = re.match(r"^\*\*\*  ch=(\d+); (.*)$", l)
+        assert m, l
+        split[int(m.group(1))].append("***  " + re.sub(r"date=\d{14}", "date=X", m.group(2)))
+    assert split == per_ch and "device 0 decodes streams 0..1" in err and "device 0 decodes streams 2..2" in err
 
 
 def test_cli_silent_stream_among_live_ones(tmp_path):
