@@ -515,8 +515,8 @@ def run_worker(args) -> int:
                        "real_time_channels": value / be.K / (12000.0 / 2592.0),
                        "real_time_channels_note": "hot-clock GPU-only arithmetic (windows/s / 4.63 at the back-to-back clock of ~2.35 GHz).  The stream decoder program itself "
                                                   "was measured at 4096 real-time streams with 0 late hops on one MI355X (tools/host_scale.py, profiles/r04_host_scale_4096*.json: "
-                                                  "worst hop latency 181-200 ms of the 210 ms limit with every stream's hop falling due together, i.e. <= 15 % margin; 4608 streams miss "
-                                                  "deadlines); a GPU that idles between hops starts each batch at 1.8-2.0 GHz (profiles/r04_idle_gap.json), so a lightly loaded "
+                                                  "worst hop latency 181-200 ms of the 210 ms limit with every stream's hop falling due together, i.e. <= 15 % margin; with unaligned stream phases 5376 streams, "
+                                                  "0 late); a GPU that idles between hops starts each batch at 1.8-2.0 GHz (profiles/r04_idle_gap.json), so a lightly loaded "
                                                   "program runs its kernels ~8 % slower than this line"},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,
