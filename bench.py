@@ -247,6 +247,22 @@ def roofline_valu(valu, lds, dom):
     return out
 
 
+def board_power_watts():
+    """Best effort: every amdgpu hwmon power reading the host exposes (sysfs, microwatts), in watts; [] when none is readable.  Context
+    for the sustained leg only - the test of a sustained clock is the in-kernel probe, not this (MI355X_MICROARCH.md, DVFS give-back)."""
+    import glob
+    out = []
+    for pat in ("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+        for path in sorted(glob.glob(pat)):
+            try:
+                out.append(round(int(open(path).read().strip()) * 1e-6, 1))
+            except (OSError, ValueError):
+                pass
+        if out:
+            break
+    return out
+
+
 def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 4, window: int = 50):
     """The same step, n_steps more times, never letting the GPU run dry: the host keeps `depth` steps queued and waits for step
     i - depth before it enqueues step i.  Every step ends with a timing marker on the decode stream; the step time of a stretch is
@@ -254,7 +270,7 @@ def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 
     (HipBackend.clock_probe: a one-wave kernel on a side stream, s_memtime / s_memrealtime).  Every rank runs the same n_steps
     (the gather of a distributed run is a collective); rank 0 reports."""
     window = max(2, min(window, n_steps // 3))
-    marks, clocks = [], {}
+    marks, clocks, power = [], {}, []
     probe_at = {depth + 2: "first", n_steps // 2: "mid", n_steps - 3: "last"} if hasattr(be, "clock_probe") else {}
     fence()
     t0 = time.perf_counter()
@@ -266,6 +282,8 @@ def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 
         marks.append(be.marker())
         if i in probe_at:
             clocks[probe_at[i]] = round(be.clock_probe(), 1)
+            if probe_at[i] == "mid":
+                power = board_power_watts()
     fence()
     wall = time.perf_counter() - t0
 
@@ -278,7 +296,7 @@ def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 
     first, last = ms["first%d" % window], ms["last%d" % window]
     return {"steps": n_steps, "seconds": wall, "queue_depth": depth, "ms_per_step": {k: round(v, 4) for k, v in ms.items()},
             "drift_last_vs_first": (last / first - 1.0) if first > 0 else None, "wall_ms_per_step": wall / n_steps * 1e3,
-            "clock_mhz": clocks or None,
+            "clock_mhz": clocks or None, "board_power_w_mid_run": power or None,
             "note": "same step and inputs as the timed region, run on after it; markers = HIP events on the decode stream; clock_mhz = shader clock read by a "
                     "one-wave probe beside the running steps (s_memtime / s_memrealtime x 100 MHz); `value` is NOT taken from this leg"}
 
@@ -291,7 +309,7 @@ def parse_args(argv=None):
     ap.add_argument("--channels", type=int, default=CHANNELS_PER_GPU, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--llr-block", type=int, default=0, help="channels per softbits->index->LDPC block (0 = library default; = channels: retain every LLR row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sustain-seconds", type=float, default=10.0,
+    ap.add_argument("--sustain-seconds", type=float, default=20.0,
                     help="after the K timed steps, keep running the same step for about this long (untimed inputs unchanged) and report the step time of its "
                          "first / middle / last 50 steps and the shader clock: `value` stays the K-step figure (0 = skip)")
     ap.add_argument("--launcher", action="store_true", help="go through the N-rank launcher even for --gpus 1 (exercises the RCCL gather path)")
