@@ -296,7 +296,10 @@ def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 
     first, last = ms["first%d" % window], ms["last%d" % window]
     return {"steps": n_steps, "seconds": wall, "queue_depth": depth, "ms_per_step": {k: round(v, 4) for k, v in ms.items()},
             "drift_last_vs_first": (last / first - 1.0) if first > 0 else None, "wall_ms_per_step": wall / n_steps * 1e3,
-            "clock_mhz": clocks or None, "board_power_w_mid_run": power or None,
+            "clock_mhz": clocks or None,
+            "board_power_w_mid_run": {"max": max(power), "every_gpu_of_the_host": power,
+                                      "note": "amdgpu hwmon power1_average of every GPU the host exposes (sysfs), read in the middle of the leg; the job's own "
+                                              "GPU is not identified - on an otherwise idle host it is the maximum"} if power else None,
             "note": "same step and inputs as the timed region, run on after it; markers = HIP events on the decode stream; clock_mhz = shader clock read by a "
                     "one-wave probe beside the running steps (s_memtime / s_memrealtime x 100 MHz); `value` is NOT taken from this leg"}
 
