@@ -227,7 +227,15 @@ int main(int argc, char* const argv[])
         for(int d = 0; d < n; d++) devices.push_back(d);
     }
     else
-        for(const std::string& d : device_list) devices.push_back(atoi(d.c_str()));
+        for(const std::string& d : device_list)
+        {
+            if(d.empty() || d.find_first_not_of("0123456789") != std::string::npos)
+            {
+                std::cerr << "--devices takes HIP device ordinals (0,1,...) or 'all', not '" << d << "'" << std::endl;
+                return 2;
+            }
+            devices.push_back(atoi(d.c_str()));
+        }
     if(devices.empty()) devices.push_back(opt.device);
     if(devices.size() > 1 && !batched)
     {

@@ -241,6 +241,8 @@ def test_devices_option_errors_and_interleaved_split(exe, tmp_path):
     assert r.returncode == 2 and "--devices splits the streams" in r.stderr.decode()
     p = tmp_path / "a.s16"
     p.write_bytes(marked_stream(2, 1).tobytes())
+    r = subprocess.run([exe, f"--inputs={p},{p}", "--devices=0,gpu1"], capture_output=True, timeout=60, env=dict(os.environ, MSK144_STUB_DEVICES="2"))
+    assert r.returncode == 2 and "not 'gpu1'" in r.stderr.decode()
     r = subprocess.run([exe, f"--inputs={p},{p}", "--devices=0,5"], capture_output=True, timeout=60, env=dict(os.environ, MSK144_STUB_DEVICES="2"))
     assert r.returncode == 2 and "device 5: device ordinal out of range" in r.stderr.decode()
     # more devices than streams: the surplus devices get no loop; --devices=all asks the library
