@@ -9,6 +9,7 @@
 #include "stream_loop.h"
 
 #include <getopt.h>
+#include <signal.h>
 #include <sys/resource.h>
 
 #include <algorithm>
@@ -89,6 +90,13 @@ void warn_if_late(long long ms)
         std::cerr << "Warning: Working loop takes too much time: " << ms << " ms"
                   << " of " << soft_limit_ms << " ms max." << std::endl;
     }
+}
+
+// SIGINT / SIGTERM: ask the loops to finish what is in flight and leave in order (no SA_RESTART: a blocking fread of the single-stream
+// or interleaved reader returns short and ends its loop the usual way)
+void on_stop_signal(int)
+{
+    g_stop_requested.store(true, std::memory_order_relaxed);
 }
 
 // one share of the input streams: the loop of `device` decodes global streams [first, first + count)
@@ -368,6 +376,13 @@ int main(int argc, char* const argv[])
             return 2;
         }
     }
+    {
+        struct sigaction sa{};
+        sa.sa_handler = on_stop_signal;
+        sigemptyset(&sa.sa_mask);
+        sigaction(SIGINT, &sa, nullptr);
+        sigaction(SIGTERM, &sa, nullptr);
+    }
     const auto run_since = Clock::now();
     for(auto& l : loops) l->start();
 
@@ -404,6 +419,7 @@ int main(int argc, char* const argv[])
     for(auto& l : loops) rc = std::max(rc, l->join());
     if(rc != 0) return rc;
 
+    if(g_stop_requested.load()) std::cerr << "msk144hipdecoder: stopped by signal; hops in flight were finished" << std::endl;
     long total_hops = 0, total_late = 0, batches = 0, overflowed = 0;
     long long worst = 0;
     for(size_t i = 0; i < loops.size(); i++)

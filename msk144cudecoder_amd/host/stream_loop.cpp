@@ -25,6 +25,8 @@ constexpr int kSoftLimitMs = 210;  // of the 216 ms a hop lasts (main.cu:398-403
 
 }  // namespace
 
+std::atomic<bool> g_stop_requested{false};
+
 void split_streams(int n, int parts, int part, int& first, int& count)
 {
     const int base = n / parts, extra = n % parts;
@@ -233,6 +235,14 @@ bool DeviceLoop::take_fed_block(int& open_streams)
 void DeviceLoop::drain_descriptors(int& open_streams)
 {
     static thread_local std::vector<unsigned char> chunk(1 << 16);
+    if(g_stop_requested.load(std::memory_order_relaxed))
+    {
+        // operator stop: no more reads; hops that are complete still go out with the next batch, partial ones are dropped
+        for(Stream& s : st_)
+            if(!s.eof) s.eof = true;
+        open_streams = 0;
+        return;
+    }
     const bool connect_expired = ms_between(opened_at_, Clock::now()) >= lo_.connect_timeout_ms;
     for(int c = 0; c < nch_; c++)
     {

@@ -11,6 +11,7 @@
 
 #include "window_decoder.h"
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -167,6 +168,10 @@ private:
     std::thread ingest_, post_;
     LoopStats stats_;
 };
+
+// Set by the program's SIGINT / SIGTERM handler: every loop then treats its streams as ended - the hops already submitted are
+// collected and printed, the summary and "Done" follow and the program exits 0 (the reference has no handler: it dies mid-hop).
+extern std::atomic<bool> g_stop_requested;
 
 // contiguous split of n streams over `parts` loops, sizes differing by at most one (the rule of sharding.shard_channels)
 void split_streams(int n, int parts, int part, int& first, int& count);

@@ -297,3 +297,46 @@ def test_fifo_writer_that_leaves_without_writing_ends_its_stream_at_once(exe, tm
     seen = windows_seen(out.decode(), 2)
     assert seen[0] == [] and seen[1] == [(40 + k, 41 + k) for k in range(6)]
     assert "ch=0: Incomplete read error. rc=0" in err.decode()
+
+
+def test_sigterm_finishes_hops_in_flight_and_exits_in_order(exe, tmp_path):
+    """Service mode: SIGTERM (or Ctrl-C) while live FIFOs are being decoded - the loops stop reading, the hops already submitted are
+    collected and printed, the summary and "Done" follow, exit code 0 (the reference has no handler: it dies mid-hop)."""
+    import signal
+    n = 6
+    paths = [str(tmp_path / f"live{c}.fifo") for c in range(n)]
+    for p in paths:
+        os.mkfifo(p)
+    proc = subprocess.Popen([exe, "--devices=0,1", "--inputs=" + ",".join(paths)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, MSK144_STUB_DECODE_MS="5", MSK144_STUB_DEVICES="2"))
+    stop = threading.Event()
+
+    def feed(c):
+        x = marked_stream(400, 100 * c).tobytes()
+        try:
+            with open(paths[c], "wb", buffering=0) as f:
+                f.write(x[:5184 * 2])
+                off = 5184 * 2
+                while not stop.is_set() and off < len(x):
+                    time.sleep(0.02)
+                    f.write(x[off:off + 5184])
+                    off += 5184
+        except BrokenPipeError:
+            pass
+
+    ths = [threading.Thread(target=feed, args=(c,)) for c in range(n)]
+    for t in ths:
+        t.start()
+    time.sleep(0.6)
+    proc.send_signal(signal.SIGTERM)
+    out, err = proc.communicate(timeout=30)
+    stop.set()
+    for t in ths:
+        t.join()
+    assert proc.returncode == 0, err.decode()[-1500:]
+    assert out.decode().strip().endswith("Done") and "stopped by signal" in err.decode()
+    seen = windows_seen(out.decode(), n)
+    for c in range(n):
+        assert len(seen[c]) >= 5 and seen[c] == [(100 * c + k, 100 * c + k + 1) for k in range(len(seen[c]))], c     # a prefix of the stream, in order
+    m = re.search(r"msk144hipdecoder: (\d+) batches, (\d+) stream hops", err.decode())
+    assert m and int(m.group(2)) == sum(len(seen[c]) for c in range(n))
