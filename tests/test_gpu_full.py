@@ -250,3 +250,28 @@ def test_maximum_grid_single_channel(orc, hip, parity_report):
     assert {bytes(m1), bytes(m2)} <= parity.decoded_messages(items_g)
     assert np.array_equal(res["item"], np.nonzero(items_g["is_message_present"])[0])
     parity_report("maximum_grid_F2001_D8", dict(scan=rep, softbits=sb, ldpc=ld, decodes=int(len(res))))
+
+
+def test_channel_sharded_decode_equals_unsharded(hip):
+    """the path shards by channel.  2048 deep-configuration channels decoded by ONE handle, and the same channels as
+    four shards of 512 on four handles with msk144_set_channel_base = first channel of the shard (what rank r of a 4-GPU run, or the
+    r-th device loop, does): the concatenated shard records are the unsharded records, byte for byte, global channel ids included."""
+    import bench
+    from msk144cudecoder_amd import sharding
+    wins, truth = bench.make_inputs(3, 2048)
+    with hip.HipDecoder(channels=2048, max_results=1 << 20, **DEEP) as d:
+        d.submit_audio(wins[1])
+        d.decode()
+        whole = d.results().copy()
+    assert len(whole) > 1000 and len({int(c) for c in whole["channel"]}) > 100
+    parts = []
+    for r in range(4):
+        lo, cnt = sharding.shard_channels(2048, r, 4)
+        with hip.HipDecoder(channels=cnt, max_results=1 << 20, **DEEP) as d:
+            d.set_channel_base(lo)
+            d.submit_audio(wins[1, lo:lo + cnt])
+            d.decode()
+            rec = d.results().copy()
+        assert len(rec) == 0 or (rec["channel"].min() >= lo and rec["channel"].max() < lo + cnt)
+        parts.append(rec)
+    assert np.concatenate(parts).tobytes() == whole.tobytes()
