@@ -9,8 +9,12 @@
 #include "stream_loop.h"
 
 #include <getopt.h>
+#include <poll.h>
 #include <signal.h>
 #include <sys/resource.h>
+#include <unistd.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <chrono>
@@ -52,8 +56,8 @@ void show_help(const char* prog)
     std::cout << "                   --hop-timeout-ms=N          With --inputs: how long a batch waits for further streams once the first one has a hop ready (a batch costs what its streams cost, so small batches are cheap and keep the latency of each stream low). Default=20." << std::endl;
     std::cout << "                   --connect-timeout-ms=N      With --inputs: how long a FIFO may stay without a writer before it counts as ended. Default=10000." << std::endl;
     std::cout << "                   --skip-wav-header           Drop the first 44 bytes of every stream (the reference decodes a RIFF header as 22 samples). Default off." << std::endl;
-    std::cout << "                   --reference-decode-cache    Reproduce the reference's per-window text cache, whose comparator is always false: every decode of a window prints the text of the first one. Default: each distinct payload gets its own text." << std::endl;
-    std::cout << "                   --strict-decode             Accepted for compatibility (this is the default now)." << std::endl;
+    std::cout << "                   --strict-decode             Unpack every distinct 77-bit payload of a window on its own. Default off: like the reference, whose per-window text cache has a comparator that is always false, every decode of a window prints the text of the window's first accepted candidate (or nothing when that one does not unpack)." << std::endl;
+    std::cout << "                   --reference-decode-cache    Accepted for compatibility (the reference's behaviour is the default)." << std::endl;
     std::cout << "                   --print-bits                Append the 77-bit payload to each output line." << std::endl;
     std::cout << "                   --device=N                  HIP device ordinal. Default=0." << std::endl;
     std::cout << "                   --devices=N1,N2,...|all     With --inputs/--interleaved: split the streams contiguously over these devices; each device gets its own ingest and post-processing threads, ch=<index> stays the global stream number. An ordinal may repeat (two independent loops on one GPU)." << std::endl;
@@ -92,11 +96,31 @@ void warn_if_late(long long ms)
     }
 }
 
-// SIGINT / SIGTERM: ask the loops to finish what is in flight and leave in order (no SA_RESTART: a blocking fread of the single-stream
-// or interleaved reader returns short and ends its loop the usual way)
+// SIGINT / SIGTERM in the multi-stream modes: ask the loops to finish what is in flight and leave in order.  The handler only sets the
+// flag; every place that can sleep - the --inputs poll, the --interleaved reader below and DeviceLoop::feed()'s back-pressure wait - looks at
+// it at least every 50 ms, so the stop does not depend on where the signal lands.  The single-stream loop returns before the handlers
+// are installed and keeps the reference's behaviour (default action).
 void on_stop_signal(int)
 {
     g_stop_requested.store(true, std::memory_order_relaxed);
+}
+
+// --interleaved reader: up to n bytes of stdin, waiting in slices of 50 ms so that a stop request is seen whether stdin is a slow pipe
+// (poll times out) or a source that never blocks (checked before every read).  Short count = end of input or stop.
+size_t read_stdin(unsigned char* dst, size_t n)
+{
+    size_t got = 0;
+    while(got < n && !g_stop_requested.load(std::memory_order_relaxed))
+    {
+        pollfd p{0, POLLIN, 0};
+        const int pr = poll(&p, 1, 50);
+        if(pr < 0 && errno != EINTR) break;
+        if(pr <= 0) continue;
+        const ssize_t r = read(0, dst + got, n - got);
+        if(r > 0) got += static_cast<size_t>(r);
+        else if(r == 0 || (errno != EINTR && errno != EAGAIN)) break;
+    }
+    return got;
 }
 
 // one share of the input streams: the loop of `device` decodes global streams [first, first + count)
@@ -388,20 +412,22 @@ int main(int argc, char* const argv[])
 
     if(interleaved > 0)
     {
-        // one block per hop on stdin: the hop of stream 0, then of stream 1, ... (blocking read, like the reference's fread); every
-        // loop receives the slice of its own streams
+        // one block per hop on stdin: the hop of stream 0, then of stream 1, ... (the reference's fread, but interruptible); every
+        // loop receives the slice of its own streams.  A stop request ends the reader at the next block boundary at the latest: the
+        // blocks already handed over are decoded and printed.
         if(skip_wav)
         {
             unsigned char hdr[44];
-            if(fread(hdr, 1, sizeof(hdr), stdin) != sizeof(hdr)) printer.log("Incomplete read error. rc=0");
+            if(read_stdin(hdr, sizeof(hdr)) != sizeof(hdr) && !g_stop_requested.load()) printer.log("Incomplete read error. rc=0");
         }
         std::vector<unsigned char> block;
         bool first_block = true;
-        while(true)
+        while(!g_stop_requested.load(std::memory_order_relaxed))
         {
             const size_t need = first_block ? win_bytes : half;
             block.resize(need * nch);
-            const size_t got = fread(block.data(), 1, block.size(), stdin);
+            const size_t got = read_stdin(block.data(), block.size());
+            if(g_stop_requested.load(std::memory_order_relaxed)) break;  // a partial block is dropped, like a partial hop of --inputs
             if(got != block.size())
             {
                 printer.log("Incomplete read error. rc=" + std::to_string(got / unit));

@@ -23,9 +23,18 @@ double ms_between(Clock::time_point a, Clock::time_point b)
 
 constexpr int kSoftLimitMs = 210;  // of the 216 ms a hop lasts (main.cu:398-403)
 
+// A bounded wait for loops that also watch a flag no one notifies for (the signal handler's).  Against the system clock on purpose:
+// wait_for() goes through pthread_cond_clockwait, which gcc 11's ThreadSanitizer does not intercept (it then reports the re-acquired
+// mutex as a double lock); a wall-clock jump costs at most one early or late wake-up of a loop that re-checks its condition anyway.
+void wait_50ms(std::condition_variable& cv, std::unique_lock<std::mutex>& lk)
+{
+    cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(50));
+}
+
 }  // namespace
 
 std::atomic<bool> g_stop_requested{false};
+std::atomic<bool> g_loop_failed{false};
 
 void split_streams(int n, int parts, int part, int& first, int& count)
 {
@@ -98,6 +107,10 @@ bool DeviceLoop::open_inputs(const std::vector<std::string>& paths)
 void DeviceLoop::fail(const std::string& what)
 {
     out_.log("msk144hip: " + what);
+    // the sibling loops of a multi-device run must not keep the process alive until their own streams end: they stop reading, finish
+    // the hops in flight and the program exits with this loop's status
+    g_loop_failed.store(true, std::memory_order_relaxed);
+    g_stop_requested.store(true, std::memory_order_relaxed);
     {
         std::lock_guard<std::mutex> lk(mu_);
         failed_ = true;
@@ -129,14 +142,17 @@ void DeviceLoop::start()
 bool DeviceLoop::feed(const unsigned char* data, size_t bytes_per_stream)
 {
     std::unique_lock<std::mutex> lk(feed_mu_);
-    feed_cv_.wait(lk, [&] {
-        if(feed_q_.size() < 2) return true;
-        std::lock_guard<std::mutex> g(mu_);
-        return failed_;
-    });
+    // back-pressure: at most two blocks queued.  The wait wakes every 50 ms for the stop flag (set from a signal handler, which
+    // cannot notify a condition variable).
+    while(true)
     {
-        std::lock_guard<std::mutex> g(mu_);
-        if(failed_) return false;
+        if(g_stop_requested.load(std::memory_order_relaxed)) return false;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if(failed_) return false;
+        }
+        if(feed_q_.size() < 2) break;
+        wait_50ms(feed_cv_, lk);
     }
     feed_q_.emplace_back(data, data + bytes_per_stream * static_cast<size_t>(nch_));
     feed_bytes_.push_back(bytes_per_stream);
@@ -198,11 +214,17 @@ bool DeviceLoop::take_fed_block(int& open_streams)
     bool ended = false;
     {
         std::unique_lock<std::mutex> lk(feed_mu_);
-        feed_cv_.wait(lk, [&] {
-            if(!feed_q_.empty() || feed_eof_) return true;
-            std::lock_guard<std::mutex> g(mu_);
-            return failed_;
-        });
+        while(true)
+        {
+            if(!feed_q_.empty() || feed_eof_) break;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if(failed_) break;
+            }
+            // a stop request reaches this loop through the reader (it stops feeding and calls feed_end()); the timed wait only
+            // bounds how long a lost wake-up could last
+            wait_50ms(feed_cv_, lk);
+        }
         if(!feed_q_.empty())
         {
             block = std::move(feed_q_.front());

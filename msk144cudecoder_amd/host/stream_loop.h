@@ -172,6 +172,8 @@ private:
 // Set by the program's SIGINT / SIGTERM handler: every loop then treats its streams as ended - the hops already submitted are
 // collected and printed, the summary and "Done" follow and the program exits 0 (the reference has no handler: it dies mid-hop).
 extern std::atomic<bool> g_stop_requested;
+// Set by DeviceLoop::fail() together with g_stop_requested: the stop was caused by a failing loop, not by the operator.
+extern std::atomic<bool> g_loop_failed;
 
 // contiguous split of n streams over `parts` loops, sizes differing by at most one (the rule of sharding.shard_channels)
 void split_streams(int n, int parts, int part, int& first, int& count);

@@ -27,11 +27,11 @@ struct DecoderOptions
     int device = 0;
     int channels = 1;  // independent input streams decoded together (the reference: 1)
     // The reference keys its per-window decode cache with a comparator that is always false (main.cu:437-445), so every
-    // accepted candidate of a window receives the text - or the unpack failure - of the FIRST accepted candidate: one CRC-13
-    // false positive at a lower frequency bin silences every genuine decode of that window, and a second station is printed
-    // with the first one's text.  false (default): every distinct payload is unpacked on its own.  true
-    // (--reference-decode-cache): reproduce the reference, for byte-for-byte stdout parity on inputs where it matters.
-    bool reference_cache_quirk = false;
+    // accepted candidate of a window receives the text - or the unpack failure - of the FIRST accepted candidate (and only that
+    // one reaches unpack77, i.e. the callsign hash tables): one CRC-13 false positive at a lower frequency bin silences every
+    // genuine decode of that window, and a second station is printed with the first one's text.  true (default): reproduce the
+    // reference - same arguments, same stdout.  false (--strict-decode): every distinct payload is unpacked on its own.
+    bool reference_cache_quirk = true;
     bool print_bits = false;  // append the 77-bit payload to each line (debug)
     bool profile = false;     // record per-stage device times (HIP events; --timing)
     int max_results = 0;      // --max-results: capacity of the compact decode list per hop; 0 = 256 per stream + 131072

@@ -42,9 +42,11 @@ def windows_of(stream: np.ndarray, read_mode: int):
         s += hop
 
 
-def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, quirk: bool = False, threads: int = 8, mask_date: bool = True,
+def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, quirk: bool = True, threads: int = 8, mask_date: bool = True,
                   payloads: set = None):
-    """All output lines (without the final 'Done') the reference program would print for `stream`.  `payloads`, when given, collects
+    """All output lines (without the final 'Done') the reference program would print for `stream`.  `quirk` (default, as in the
+    program): the reference's per-window text cache (main.cu:437-445, 497-504) - every accepted candidate of a window gets the text, or
+    the unpack failure, of the window's first accepted candidate; False = msk144hipdecoder --strict-decode (each payload on its own).  `payloads`, when given, collects
     the 77-bit payload (as a '0'/'1' string) of every accepted candidate of every window - the text-independent artefact."""
     H = C.CDLL(HOST_SO)
     H.msk144host_table_new.restype = C.c_void_p
@@ -73,12 +75,12 @@ def decode_stream(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_me
     return out
 
 
-def printed_payloads(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, threads: int = 8) -> set:
+def printed_payloads(stream: np.ndarray, cfg: dict, read_mode: int = 1, analytic_method: int = 2, threads: int = 8, quirk: bool = True) -> set:
     """The 77-bit payloads `msk144hipdecoder --print-bits` would print for `stream`: accepted payloads whose own text (decoded with
     a fresh hash table, as the program does for that option) is the text of an output line.  A payload the text layer rejects is
-    accepted by the decoder but never printed."""
+    accepted by the decoder but never printed; in the reference mode (`quirk`) neither is one whose window started with another text."""
     acc = set()
-    lines = decode_stream(stream, cfg, read_mode, analytic_method, threads=threads, payloads=acc)
+    lines = decode_stream(stream, cfg, read_mode, analytic_method, quirk=quirk, threads=threads, payloads=acc)
     texts = set(re.findall(r"msg='(.*)'; $", "\n".join(lines), flags=re.M))
     H = C.CDLL(HOST_SO)
     H.msk144host_table_new.restype = C.c_void_p
@@ -104,15 +106,15 @@ def main():
     ap.add_argument("--read-mode", type=int, default=1)
     ap.add_argument("--analytic-method", type=int, default=2)
     ap.add_argument("--nbadsync-threshold", type=int, default=1)
-    ap.add_argument("--reference-decode-cache", action="store_true")
-    ap.add_argument("--strict-decode", action="store_true", help="accepted for compatibility: per-payload decode is the default")
+    ap.add_argument("--reference-decode-cache", action="store_true", help="accepted for compatibility: the reference's cache behaviour is the default")
+    ap.add_argument("--strict-decode", action="store_true", help="unpack every distinct payload of a window on its own")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     a = ap.parse_args()
     center = a.center_frequency if a.center_frequency is not None else (1500.0 if a.read_mode == 1 else 0.0)
     raw = sys.stdin.buffer.read()
     stream = np.frombuffer(raw, dtype=np.int16 if a.read_mode == 1 else np.int8)
     cfg = dict(center=center, width=a.search_width, step=a.search_step, depth=a.scan_depth, nbadsync_threshold=a.nbadsync_threshold)
-    for line in decode_stream(stream, cfg, a.read_mode, a.analytic_method, quirk=a.reference_decode_cache, threads=a.threads, mask_date=False):
+    for line in decode_stream(stream, cfg, a.read_mode, a.analytic_method, quirk=not a.strict_decode, threads=a.threads, mask_date=False):
         print(line)
     print("Done")
 

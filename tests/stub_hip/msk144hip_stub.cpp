@@ -34,6 +34,8 @@ struct msk144_handle
     int cur = 0;
     int active[MSK144_SLOTS] = {0, 0};  // windows the hop in each slot covers
     int decode_ms = 5;
+    int fail_after = -1;  // MSK144_STUB_FAIL_DEVICE / MSK144_STUB_FAIL_AFTER: the n-th hop pushed on that device fails
+    int pushed = 0;
     bool overflow[MSK144_SLOTS] = {false, false};
     std::string error;
 };
@@ -85,6 +87,12 @@ int msk144_create(const msk144_params* p, msk144_handle** out)
     auto* h = new msk144_handle();
     h->p = *p;
     if(const char* e = std::getenv("MSK144_STUB_DECODE_MS")) h->decode_ms = std::atoi(e);
+    if(const char* d = std::getenv("MSK144_STUB_FAIL_DEVICE"))
+        if(std::atoi(d) == p->device)
+        {
+            const char* n = std::getenv("MSK144_STUB_FAIL_AFTER");
+            h->fail_after = n ? std::atoi(n) : 0;
+        }
     *out = h;
     return MSK144_OK;
 }
@@ -178,6 +186,11 @@ int msk144_push_hops(msk144_handle* h, int32_t s, int32_t n)
     {
         h->error = "stub: slot submitted again before its results were fetched";
         return MSK144_ESTATE;
+    }
+    if(h->fail_after >= 0 && h->pushed++ >= h->fail_after)
+    {
+        h->error = "stub: injected device failure";
+        return MSK144_EHIP;
     }
     const size_t half = MSK144_HOP_SAMPLES;
     for(int j = 0; j < n; j++)

@@ -29,6 +29,29 @@ def _run(args, data):
     return p.returncode, p.stdout.decode(), p.stderr.decode()
 
 
+def _lines(out):
+    lines = out.strip().split("\n")
+    assert lines[-1] == "Done"
+    return [re.sub(r"date=\d{14}", "date=X", l) for l in lines[:-1]]
+
+
+def _both_modes(orc, args, stream, cfg, read_mode=1):
+    """Identical arguments => identical stdout (date= aside): the DEFAULT run against the oracle-driven decoder with the reference's
+    per-window text cache (main.cu:437-445, 497-504), --strict-decode against the per-payload decode, and --reference-decode-cache
+    (accepted for compatibility) changes nothing.  Returns (default lines, strict lines, stderr of the default run)."""
+    rc, out, err = _run(args, stream.tobytes())
+    assert rc == 0, err
+    got = _lines(out)
+    assert got == _expected_lines(orc, stream, cfg, read_mode, quirk=True)
+    rc, out_s, err_s = _run(args + ["--strict-decode"], stream.tobytes())
+    assert rc == 0, err_s
+    strict = _lines(out_s)
+    assert strict == _expected_lines(orc, stream, cfg, read_mode, quirk=False)
+    rc, out_c, _ = _run(args + ["--reference-decode-cache"], stream.tobytes())
+    assert rc == 0 and _lines(out_c) == got
+    return got, strict, err
+
+
 def test_cli_audio_stream(orc):
     rng = np.random.default_rng(77)
     n = 5184 + 4 * 2592
@@ -37,25 +60,46 @@ def test_cli_audio_stream(orc):
     stream = synth.synth_audio(n, pings, 1000.0, rng)
     cfg = dict(center=1500.0, width=20.0, step=1.0, depth=6, nbadsync_threshold=2)
     args = ["--search-width=20", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=2"]
-    rc, out, err = _run(args + ["--strict-decode"], stream.tobytes())
-    assert rc == 0, err
-    lines = out.strip().split("\n")
-    assert lines[-1] == "Done"
-    got = [re.sub(r"date=\d{14}", "date=X", l) for l in lines[:-1]]
+    got, strict, err = _both_modes(orc, args, stream, cfg)
     assert "Actual parameters:" in err and "Incomplete read error. rc=0" in err
-    want = _expected_lines(orc, stream, cfg, 1, quirk=False)
-    assert len(want) >= 2
-    assert got == want
+    assert len(got) >= 2
     # every line has the reference's field layout (main.cu:409-417)
     pat = re.compile(r"^\*\*\*  snr=[ -]?\d+; f0=\s*[\d.]+; num_avg=\d; nbadsync=\d+; pattern_idx=\d; date=X; msg='.*'; $")
-    assert all(pat.match(l) for l in got)
-    # the default is the per-payload decode; --strict-decode is still accepted and changes nothing
-    rc, out1, _ = _run(args, stream.tobytes())
-    assert [re.sub(r"date=\d{14}", "date=X", l) for l in out1.strip().split("\n")[:-1]] == want
-    # --reference-decode-cache reproduces the reference's first-candidate cache behaviour
-    rc, out2, _ = _run(args + ["--reference-decode-cache"], stream.tobytes())
-    got2 = [re.sub(r"date=\d{14}", "date=X", l) for l in out2.strip().split("\n")[:-1]]
-    assert got2 == _expected_lines(orc, stream, cfg, 1, quirk=True)
+    assert all(pat.match(l) for l in got + strict)
+
+
+def test_cli_two_payloads_in_one_window(orc):
+    """Two stations in the SAME window (main.cu:480-525 walks the items in index order, lowest frequency bin first): the reference's cache
+    hands the second station the first one's text, so the default run prints ONE text for the window (the lower bin's) where
+    --strict-decode prints both - each mode line for line what the oracle-driven decoder predicts."""
+    rng = np.random.default_rng(79)
+    lo, hi = pack77.pack_standard("CQ", "K1ABC", "FN42"), pack77.pack_standard("W9XYZ", "G4ABC", "-07")
+    pings = [synth.Ping(hi, 700, 5, 1506.0, 6.0, 0.3), synth.Ping(lo, 900, 5, 1494.0, 6.0, 1.1)]
+    stream = synth.synth_audio(5184, pings, 1000.0, rng)       # exactly one window
+    cfg = dict(center=1500.0, width=20.0, step=1.0, depth=6, nbadsync_threshold=2)
+    args = ["--search-width=20", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=2"]
+    got, strict, _ = _both_modes(orc, args, stream, cfg)
+    text = lambda ls: sorted({re.search(r"msg='(.*)'; $", l).group(1) for l in ls})
+    assert text(strict) == ["CQ K1ABC FN42", "W9XYZ G4ABC -07"]
+    assert text(got) == ["CQ K1ABC FN42"]                      # the window's first accepted candidate sits in the lowest decoded bin
+
+
+def test_cli_first_candidate_fails_the_type_gate(orc):
+    """The window's first accepted candidate carries i3 = 3, which decode_message refuses before unpack77 (decode_softbits.cpp:25-30):
+    the reference caches that failure for the whole window (main.cu:497-504), so the default run prints nothing for it although a
+    valid message sits a few bins higher; --strict-decode prints the valid one.  The second window of the stream, which holds only the
+    valid station, prints in both modes."""
+    rng = np.random.default_rng(83)
+    bad = synth.random_message(rng).copy()
+    bad[74:77] = (0, 1, 1)                                      # i3 = 3
+    good = pack77.pack_standard("CQ", "DL1ABC", "JO62")
+    pings = [synth.Ping(bad, 200, 2, 1493.0, 7.0, 0.2), synth.Ping(good, 2200, 3, 1507.0, 7.0, 0.9), synth.Ping(good, 5184 + 600, 5, 1507.0, 7.0, 0.5)]
+    stream = synth.synth_audio(5184 + 2 * 2592, pings, 1000.0, rng)
+    cfg = dict(center=1500.0, width=20.0, step=1.0, depth=6, nbadsync_threshold=2)
+    args = ["--search-width=20", "--search-step=1", "--scan-depth=6", "--nbadsync-threshold=2"]
+    got, strict, _ = _both_modes(orc, args, stream, cfg)
+    assert strict and all("msg='CQ DL1ABC JO62'" in l for l in strict)
+    assert len(strict) == 3 and got == strict[1:]               # the first window is silenced by the cached failure, the later two are not
 
 
 def test_cli_iq_and_option_quirks(orc):
@@ -63,10 +107,8 @@ def test_cli_iq_and_option_quirks(orc):
     msg = synth.random_message(rng)
     stream = synth.synth_iq(5184 + 2592, [synth.Ping(msg, 800, 6, 2.0, 4.0, 0.1)], 20.0, rng)
     cfg = dict(center=0.0, width=12.0, step=2.0, depth=4, nbadsync_threshold=1)
-    rc, out, err = _run(["--read-mode=2", "--search-width=12", "--strict-decode"], stream.tobytes())
-    assert rc == 0 and out.strip().endswith("Done")
-    got = [re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]]
-    assert got == _expected_lines(orc, stream, cfg, 2, quirk=False) and len(got) >= 1
+    got, _, _ = _both_modes(orc, ["--read-mode=2", "--search-width=12"], stream, cfg, read_mode=2)
+    assert len(got) >= 1
     # short input: error on stderr, Done on stdout, exit 0 (main.cu:274-278,424)
     rc, out, err = _run([], b"\x00" * 100)
     assert rc == 0 and out.strip() == "Done" and "Incomplete read error. rc=50" in err
@@ -81,7 +123,7 @@ def test_cli_multi_stream_equals_single_streams(tmp_path):
     """--inputs=a,b,c decodes the streams as one GPU batch per hop; each channel's lines must be exactly what
     the single-stream program prints for that file (streams of different length end independently)."""
     rng = np.random.default_rng(80)
-    args = ["--search-width=16", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2", "--strict-decode"]
+    args = ["--search-width=16", "--search-step=2", "--scan-depth=6", "--nbadsync-threshold=2"]
     files, singles = [], []
     for i, n_hops in enumerate((4, 2, 5)):
         n = 5184 + n_hops * 2592
@@ -203,15 +245,12 @@ def test_cli_silent_stream_among_live_ones(tmp_path):
 
 def test_cli_s1_stream_light_config(orc):
     """BASELINE configs[0]/[1] stand-in (demo/0001.wav is absent): the S1 functional stream at the README's
-    'optimal scan' options, HIP program vs the oracle-driven CPU decoder, line for line."""
+    'optimal scan' options, HIP program vs the oracle-driven CPU decoder, line for line - the default run in the reference's mode,
+    --strict-decode in the per-payload mode."""
     stream, pings = synth.stream_s1(0, seconds=8.0, n_pings=4, span=40.0)
     cfg = dict(center=1500.0, width=100.0, step=2.0, depth=3, nbadsync_threshold=1)
-    args = ["--search-width=100", "--scan-depth=3"]
-    rc, out, err = _run(args + ["--strict-decode"], stream.tobytes())
-    assert rc == 0, err
-    got = [re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]]
-    want = _expected_lines(orc, stream, cfg, 1, quirk=False)
-    assert got == want
+    got, strict, err = _both_modes(orc, ["--search-width=100", "--scan-depth=3"], stream, cfg)
+    assert len(got) >= 2
     assert "Left Boundary: 1450Hz" in err and "Right Boundary: 1550Hz" in err
 
 
@@ -219,7 +258,8 @@ def test_cli_s1_stream_deep_config(orc):
     """BASELINE configs[1] stand-in (demo/0001.wav is absent): an S1 stream through stdin -> stdout at the deep options of
     README.md:65-67 (--search-width=500 --search-step=1 --scan-depth=6 --nbadsync-threshold=3: F=501, 24 048 candidates per window)
     - window ring, GPU path, SNR tracker, text layer and per-window filter - line for line against the oracle-driven CPU decoder
-    (main.cu:261-422), and, independent of the text layer, the printed 77-bit payloads against the oracle's accepted payloads."""
+    (main.cu:261-422) in BOTH modes (default = the reference's text cache, --strict-decode = per payload), and, independent of the text
+    layer, the printed 77-bit payloads against the oracle's accepted payloads."""
     from oracle import oracle_cli
     stream, pings = synth.stream_s1(1, seconds=3.5, n_pings=3, span=240.0)
     cfg = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
@@ -227,11 +267,14 @@ def test_cli_s1_stream_deep_config(orc):
     rc, out, err = _run(args, stream.tobytes())
     assert rc == 0, err
     assert "Left Boundary: 1250Hz" in err and "Right Boundary: 1750Hz" in err and "Softbit-kernel CUDA blocks: 501*48=24048" in err
-    got = [re.sub(r"date=\d{14}", "date=X", l) for l in out.strip().split("\n")[:-1]]
     accepted = set()
-    want = oracle_cli.decode_stream(stream, cfg, 1, 2, quirk=False, threads=16, payloads=accepted)
-    assert got == want and len(want) >= 2
-    rc, out, err = _run(args + ["--print-bits"], stream.tobytes())
+    want = oracle_cli.decode_stream(stream, cfg, 1, 2, quirk=True, threads=16, payloads=accepted)
+    assert _lines(out) == want and len(want) >= 2
+    rc, out, err = _run(args + ["--strict-decode"], stream.tobytes())
+    assert rc == 0, err
+    want_strict = oracle_cli.decode_stream(stream, cfg, 1, 2, quirk=False, threads=16)
+    assert _lines(out) == want_strict and len(want_strict) >= len(want)
+    rc, out, err = _run(args + ["--strict-decode", "--print-bits"], stream.tobytes())
     assert rc == 0, err
     printed = set(re.findall(r"bits='([01]{77})'", out))
     sent = {"".join(str(int(b)) for b in p.msg77) for p in pings}

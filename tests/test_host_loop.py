@@ -340,3 +340,123 @@ def test_sigterm_finishes_hops_in_flight_and_exits_in_order(exe, tmp_path):
         assert len(seen[c]) >= 5 and seen[c] == [(100 * c + k, 100 * c + k + 1) for k in range(len(seen[c]))], c     # a prefix of the stream, in order
     m = re.search(r"msk144hipdecoder: (\d+) batches, (\d+) stream hops", err.decode())
     assert m and int(m.group(2)) == sum(len(seen[c]) for c in range(n))
+
+
+def _interleaved_blocks(n, hops):
+    streams = [marked_stream(hops, 300 * c) for c in range(n)]
+    blocks = [np.stack([s[:5184] for s in streams]).tobytes()]
+    for h in range(hops):
+        blocks.append(np.stack([s[5184 + h * 2592:5184 + (h + 1) * 2592] for s in streams]).tobytes())
+    return blocks
+
+
+@pytest.mark.parametrize("decode_ms,source", [("5", "file"), ("400", "file"), ("5", "slow_pipe")])
+def test_sigterm_stops_an_interleaved_run_wherever_the_reader_is(exe, tmp_path, decode_ms, source):
+    """the handler only sets a flag, so the stop must not depend on the signal landing inside a blocking read.  Three places
+    the --interleaved reader can be in: stdin is a file that never blocks (`cat big.raw | ...`: the reader lives in feed()'s
+    back-pressure wait or between reads), the same with a slow "GPU" (always in the back-pressure wait), and a pipe that delivers
+    a block every 100 ms (the reader sleeps in poll).  Each time: exit 0 within two seconds, "stopped by signal", "Done", the windows
+    printed are a prefix of every stream, in order."""
+    import signal
+    n, hops = 4, 4000
+    blocks = _interleaved_blocks(n, 40)
+    if source == "file":
+        path = tmp_path / "big.raw"
+        with open(path, "wb") as f:
+            f.write(blocks[0])
+            for k in range(hops):
+                f.write(blocks[1 + k % 40])               # ~80 MB: minutes of decoding at 5 ms per hop, nowhere near done when the signal comes
+        stdin = open(path, "rb")
+    else:
+        stdin = subprocess.PIPE
+    proc = subprocess.Popen([exe, f"--interleaved={n}", "--devices=0,1"], stdin=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, MSK144_STUB_DECODE_MS=decode_ms, MSK144_STUB_DEVICES="2"))
+    stop = threading.Event()
+
+    def slow_writer():
+        try:
+            proc.stdin.write(blocks[0])
+            k = 0
+            while not stop.is_set():
+                time.sleep(0.1)
+                proc.stdin.write(blocks[1 + k % 40])
+                proc.stdin.flush()
+                k += 1
+        except (BrokenPipeError, ValueError):
+            pass
+
+    th = None
+    if source == "slow_pipe":
+        th = threading.Thread(target=slow_writer)
+        th.start()
+    time.sleep(1.0)
+    t0 = time.monotonic()
+    proc.send_signal(signal.SIGTERM)
+    try:
+        out, err = proc.communicate(timeout=20) if source == "file" else (None, None)
+        if source != "file":
+            # communicate() would close stdin, which alone would end the reader: wait for the exit first
+            proc.wait(timeout=20)
+            stop.set()
+            th.join()
+            out, err = proc.stdout.read(), proc.stderr.read()
+    finally:
+        stop.set()
+        if proc.poll() is None:
+            proc.kill()
+    took = time.monotonic() - t0
+    if source == "file":
+        stdin.close()
+    assert proc.returncode == 0, err.decode()[-1500:]
+    assert took < 2.0 + 4 * int(decode_ms) / 1000.0, took     # two queued blocks + two slots in flight may still finish
+    assert out.decode().strip().endswith("Done") and "stopped by signal" in err.decode()
+    assert "Incomplete read error" not in err.decode()       # a stop is not an end of input
+    seen = windows_seen(out.decode(), n)
+    for c in range(n):
+        got = len(seen[c])
+        assert got >= 1 and got < hops
+        if source == "slow_pipe":
+            assert seen[c] == [(300 * c + k, 300 * c + k + 1) for k in range(got)], c
+
+
+def test_a_failing_device_loop_stops_its_siblings(exe, tmp_path):
+    """in a multi-device run over live FIFOs a loop whose device fails used to leave the other loops decoding until their
+    writers went away - the process never exited.  Now the failure is a stop request for every loop: hops in flight are finished and
+    the program exits 2 while the writers are still there."""
+    n = 4
+    paths = [str(tmp_path / f"live{c}.fifo") for c in range(n)]
+    for p in paths:
+        os.mkfifo(p)
+    proc = subprocess.Popen([exe, "--devices=0,1", "--inputs=" + ",".join(paths)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, MSK144_STUB_DECODE_MS="5", MSK144_STUB_DEVICES="2", MSK144_STUB_FAIL_DEVICE="1", MSK144_STUB_FAIL_AFTER="3"))
+    stop = threading.Event()
+
+    def feed(c):
+        x = marked_stream(2000, 100 * c).tobytes()
+        try:
+            with open(paths[c], "wb", buffering=0) as f:
+                f.write(x[:5184 * 2])
+                off = 5184 * 2
+                while not stop.is_set() and off < len(x):
+                    time.sleep(0.02)
+                    f.write(x[off:off + 5184])
+                    off += 5184
+        except BrokenPipeError:
+            pass
+
+    ths = [threading.Thread(target=feed, args=(c,)) for c in range(n)]
+    for t in ths:
+        t.start()
+    try:
+        rc = proc.wait(timeout=15)                           # exits on its own, writers still connected
+    finally:
+        stop.set()
+        if proc.poll() is None:
+            proc.kill()
+    out, err = proc.stdout.read().decode(), proc.stderr.read().decode()
+    for t in ths:
+        t.join()
+    assert rc == 2 and "injected device failure" in err, err[-1500:]
+    assert "Done" not in out
+    seen = windows_seen(out + "Done\n", n)                   # (the helper strips the text: keep the last line's trailing blank)
+    assert len(seen[0]) >= 3 and len(seen[2]) == 3           # device 0's streams ran on, device 1's got three hops through
