@@ -187,8 +187,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a)
     const int xcd = blockIdx.x & 7;
     const int tile = xcd * a.tiles_per_xcd + (blockIdx.x >> 3);
     if((blockIdx.x >> 3) >= a.tiles_per_xcd || tile >= a.total_tiles) return;
-    const int ch = tile / a.st.F;
-    const int b = tile - ch * a.st.F;
+    const int ch_rel = tile / a.st.F;  // channel inside the block [ch0, ch0 + nch) this launch covers
+    const int b = tile - ch_rel * a.st.F;
+    const int ch = a.st.ch0 + ch_rel;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -477,7 +478,7 @@ void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t str
     ScanArgs a;
     a.st = st;
     for(int i = 0; i < 12; i++) a.pp[i] = tpl.pp[i];
-    a.total_tiles = st.channels * st.F;
+    a.total_tiles = st.nch * st.F;  // the whole batch (ch0 = 0, nch = channels) or one channel block of the overlapped schedule
     a.tiles_per_xcd = (a.total_tiles + 7) / 8;
 #ifdef MSK144_PHASE_STAMPS
     a.stamps = stamp_buffer(0);
