@@ -22,7 +22,6 @@
  *   msk144_fetch_wait        D2H of what the host loop consumes)  main.cu:261-422, 474-525
  *   msk144_dump_candidates   the raw ResultItem array (parity/debug)     result_keeper.cuh:17-32,123-130
  *   msk144_destroy           ~MSK144SearchContext / deinit        msk_context.cuh:81-120
- *   msk144_set_overlap       do_decode's launch order: LDPC of one channel block beside scan/softbits of the next   main.cu:463-467
  *   msk144_device_count      cudaGetDeviceCount behind cudaSetDeviceFlags (the reference drives device 0 only; the multi-device
  *                            stream program asks how many it may split its streams over)   main.cu:115
  *   msk144_clock_probe       gpu_timer.h's role for the one figure HIP events cannot give: the shader clock a running batch
@@ -180,17 +179,6 @@ int msk144_submit_analytic(msk144_handle* h, const float* windows);
 int msk144_decode(msk144_handle* h);
 int msk144_decode_stages(msk144_handle* h, uint32_t stages);
 int msk144_synchronize(msk144_handle* h);
-
-/* Overlapped block schedule.  The reference launches scan, softbits, index and LDPC back to back on the default stream
- * (main.cu:463-467), and so does a handle by default: one kernel at a time, which is what per-stage times (msk144_stage_times) and
- * profiles need.  mode 1..3: with blocked staging (llr_block_channels < channels) the LDPC of channel block b runs on a second
- * stream of the handle beside scan + softbits + index of block b+1 (a second LLR block of llr_block_channels x items x 512 B is
- * allocated): the tails, barriers and one-wave phases of either side are filled by the other.  Results are the same records in the
- * same order; callers still see ONE stream - whatever is enqueued on the handle's stream after msk144_decode waits for both.
- * Per-stage times of an overlapped decode cover scan / softbits / index only (the LDPC runs elsewhere) and stretch, so take them
- * from a serial pass.  mode 1: second stream at default priority, 2: at the highest, 3: at the lowest priority the device offers;
- * 0: back to the serial schedule.  MSK144_ENOTRETAINED on a handle that decodes its channels as one block. */
-int msk144_set_overlap(msk144_handle* h, int32_t mode);
 
 /* Waits for the decode, copies the compact result list.  *n = number of decodes (<= cap copied). */
 int msk144_results(msk144_handle* h, msk144_result* out, int32_t cap, int32_t* n);

@@ -89,12 +89,6 @@ struct msk144_handle
     int32_t* d_streams = nullptr;
     uint8_t* d_isfirst = nullptr;
     bool ring_ready = false;
-    // msk144_set_overlap: the LDPC of channel block b runs on `ldpc_stream` beside scan / softbits / index of block b+1 on `stream`
-    int overlap = 0;
-    hipStream_t ldpc_stream = nullptr;
-    float* d_llr_b = nullptr;            // second LLR block: softbits of block b+1 must not overwrite what the LDPC of block b reads
-    std::vector<hipEvent_t> ev_ready;    // [block] index of the block done on `stream`: its LDPC may start
-    std::vector<hipEvent_t> ev_decoded;  // [block] LDPC of the block done on `ldpc_stream`: its LLR buffer may be rewritten
     // msk144_clock_probe: its own stream, so that the probe wave runs beside the decode kernels
     hipStream_t probe_stream = nullptr;
     uint64_t* d_probe = nullptr;
@@ -510,11 +504,7 @@ void msk144_destroy(msk144_handle* h)
     if(!h) return;
     (void)hipSetDevice(h->params.device);
     if(h->probe_stream) (void)hipStreamSynchronize(h->probe_stream);
-    if(h->ldpc_stream) (void)hipStreamSynchronize(h->ldpc_stream);
     if(h->stream) (void)hipStreamSynchronize(h->stream);
-    for(hipEvent_t e : h->ev_ready) (void)hipEventDestroy(e);
-    for(hipEvent_t e : h->ev_decoded) (void)hipEventDestroy(e);
-    if(h->ldpc_stream) (void)hipStreamDestroy(h->ldpc_stream);
     for(void* p : h->allocs) (void)hipFree(p);
     for(auto& sl : h->slots)
     {
@@ -637,58 +627,6 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
     h->call_id++;
     if(h->profiling) harvest_finished(h);
     const DeviceStore cur = active_store(h);
-    const int n_blocks = (cur.channels + h->llr_block - 1) / h->llr_block;
-    if(h->overlap && blocked && n_blocks >= 2 && (stages & (MSK144_STAGE_SCAN | mid)) == (MSK144_STAGE_SCAN | mid))
-    {
-        // Overlapped schedule (msk144_set_overlap).  `stream`: scan, softbits and index of block 0, 1, 2, ...; `ldpc_stream`: the
-        // LDPC of block 0, 1, 2, ... - each started by the event its index kernel records, while `stream` is already scanning and
-        // demodulating the next block into the OTHER LLR buffer.  softbits of block b+2 waits for the LDPC of block b (it reuses
-        // that buffer); the collect kernel (or whatever the caller enqueues next on `stream`) waits for the last LDPC.  The
-        // reference launches its four kernels back to back on the default stream (main.cu:463-467).
-        while(static_cast<int>(h->ev_ready.size()) < n_blocks)
-        {
-            hipEvent_t a = nullptr, b = nullptr;
-            HIP_TRY(h, hipEventCreateWithFlags(&a, hipEventDisableTiming));
-            h->ev_ready.push_back(a);
-            HIP_TRY(h, hipEventCreateWithFlags(&b, hipEventDisableTiming));
-            h->ev_decoded.push_back(b);
-        }
-        DeviceStore blk = cur;
-        const bool scan_whole = h->overlap >= 4;
-        if(scan_whole)
-        {
-            ev_begin(h, MSK144_T_SCAN);
-            launch_scan(cur, h->tpl, h->stream);
-            ev_end(h, MSK144_T_SCAN);
-        }
-        for(int b = 0; b < n_blocks; b++)
-        {
-            blk.ch0 = b * h->llr_block;
-            blk.nch = cur.channels - blk.ch0 < h->llr_block ? cur.channels - blk.ch0 : h->llr_block;
-            blk.llr = (b & 1) ? h->d_llr_b : h->st.llr;
-            if(!scan_whole)
-            {
-                ev_begin(h, MSK144_T_SCAN);
-                launch_scan(blk, h->tpl, h->stream);
-                ev_end(h, MSK144_T_SCAN);
-            }
-            if(b >= 2) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_decoded[b - 2], 0));
-            ev_begin(h, MSK144_T_SOFTBITS);
-            launch_softbits(blk, h->tpl, h->stream);
-            ev_end(h, MSK144_T_SOFTBITS);
-            ev_begin(h, MSK144_T_INDEX);
-            launch_index(blk, h->stream);
-            ev_end(h, MSK144_T_INDEX);
-            HIP_TRY(h, hipEventRecord(h->ev_ready[b], h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->ldpc_stream, h->ev_ready[b], 0));
-            launch_ldpc(blk, h->ldpc_stream);
-            HIP_TRY(h, hipEventRecord(h->ev_decoded[b], h->ldpc_stream));
-        }
-        // ldpc_stream is in order: the last block's event covers them all
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_decoded[n_blocks - 1], 0));
-    }
-    else
-    {
     if(stages & MSK144_STAGE_SCAN)
     {
         ev_begin(h, MSK144_T_SCAN);
@@ -722,7 +660,6 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
                 ev_end(h, MSK144_T_LDPC);
             }
         }
-    }
     }
     if(stages & MSK144_STAGE_COLLECT)
     {
@@ -1017,40 +954,6 @@ int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candi
     HIP_TRY(h, hipMemcpy(st.llr + off * kCodeBits, llr.data(), K * kCodeBits * 4, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemsetAsync(st.dec_flag + off, 0, K, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return MSK144_OK;
-}
-
-int msk144_set_overlap(msk144_handle* h, int32_t mode)
-{
-    if(!h) return MSK144_EINVAL;
-    if(mode < 0 || mode > 5) return fail(h, MSK144_EINVAL, "overlap mode must be 0..5");
-    int rc = msk144_synchronize(h);
-    if(rc != MSK144_OK) return rc;
-    if(mode == 0)
-    {
-        h->overlap = 0;
-        return MSK144_OK;
-    }
-    if(h->llr_block >= h->st.channels) return fail(h, MSK144_ENOTRETAINED, "the overlapped schedule pipelines channel blocks; this handle decodes its channels as one block");
-    if(mode != h->overlap && h->ldpc_stream)
-    {
-        HIP_TRY(h, hipStreamSynchronize(h->ldpc_stream));
-        HIP_TRY(h, hipStreamDestroy(h->ldpc_stream));
-        h->ldpc_stream = nullptr;
-    }
-    if(!h->ldpc_stream)
-    {
-        int lo = 0, hi = 0;  // numerically lower = higher priority
-        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const int prio = mode == 2 ? hi : ((mode == 3 || mode == 5) ? lo : 0);
-        HIP_TRY(h, hipStreamCreateWithPriority(&h->ldpc_stream, hipStreamNonBlocking, prio));
-    }
-    if(!h->d_llr_b)
-    {
-        rc = dev_alloc(h, &h->d_llr_b, static_cast<size_t>(h->llr_block) * h->st.K * kCodeBits);
-        if(rc != MSK144_OK) return rc;
-    }
-    h->overlap = mode;
     return MSK144_OK;
 }
 

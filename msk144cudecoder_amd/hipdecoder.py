@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "msk144_result_count", "msk144_results_device", "msk144_set_channel_base", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
     "msk144_input_slot", "msk144_submit_slot", "msk144_submit_slot_n", "msk144_fetch_async", "msk144_fetch_wait", "msk144_hop_slot", "msk144_push_hops",
-    "msk144_device_count", "msk144_clock_probe", "msk144_set_overlap",
+    "msk144_device_count", "msk144_clock_probe",
 )
 
 
@@ -111,7 +111,6 @@ def load_library(path: Optional[str] = None):
     L.msk144_fetch_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp)]
     L.msk144_device_count.argtypes = [C.POINTER(i32)]
     L.msk144_clock_probe.argtypes = [vp, i32, C.POINTER(C.c_float)]
-    L.msk144_set_overlap.argtypes = [vp, i32]
     if path is None:
         _lib = L
     return L
@@ -200,11 +199,6 @@ class HipDecoder:
 
     def synchronize(self):
         self._chk(self.L.msk144_synchronize(self.h))
-
-    def set_overlap(self, mode: int):
-        """0: serial schedule (one kernel at a time: stage times, profiles).  1..3: LDPC of channel block b on a second stream beside
-        scan/softbits/index of block b+1 (1 default, 2 highest, 3 lowest priority of that stream); needs blocked staging."""
-        self._chk(self.L.msk144_set_overlap(self.h, int(mode)))
 
     def result_count(self) -> int:
         n = C.c_int32()
