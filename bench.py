@@ -304,6 +304,101 @@ def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 
                     "one-wave probe beside the running steps (s_memtime / s_memrealtime x 100 MHz); `value` is NOT taken from this leg"}
 
 
+def pcie_leg(be, n_steps: int):
+    """The same step with the windows coming from pinned HOST memory (the reference's hop includes its H2D copy, main.cu:325): each
+    step is msk144_submit_slot (asynchronous H2D of the slot's 1024 windows + front end), msk144_decode, msk144_fetch_async
+    (asynchronous D2H of count + records + segment powers), pipelined over the handle's two pinned staging slots exactly as
+    msk144hipdecoder's loop drives them.  The slots are filled before the clock starts (they ARE the host buffer a reader fills).
+    Reported beside `value`, never as `value`."""
+    dec = be.dec
+    for s in range(2):
+        dec.input_slot(s)[:] = be.wins_host[s % WINDOWS_PER_CHANNEL]
+    for i in range(2):                       # both slots once, untimed
+        dec.submit_slot(i)
+        dec.decode()
+        dec.fetch_async(i)
+    for i in range(2):
+        dec.fetch_wait(i)
+    be.fence()
+    dec.stage_times(reset=True)
+    t0 = time.perf_counter()
+    records = 0
+    for i in range(n_steps):
+        s = i % 2
+        if i >= 2:
+            records = len(dec.fetch_wait(s)[0])
+        dec.submit_slot(s)
+        dec.decode()
+        dec.fetch_async(s)
+    for i in range(max(0, n_steps - 2), n_steps):
+        records = len(dec.fetch_wait(i % 2)[0])
+    be.fence()
+    el = time.perf_counter() - t0
+    st = dec.stage_times(reset=True)
+    return {"value": be.cand_per_step * n_steps / el, "unit": "candidates/s", "steps": n_steps, "ms_per_step": el / n_steps * 1e3,
+            "h2d_ms_per_step": round(st["h2d"][0], 4), "d2h_ms_per_step": round(st["d2h"][0], 4), "records_last_step": records,
+            "h2d_bytes_per_step": int(be.wins_host[0].nbytes),
+            "note": "windows in pinned host memory -> msk144_submit_slot / msk144_decode / msk144_fetch_async over the two staging slots, copies and kernels "
+                    "on the one decode stream (no copy/compute overlap); timed from the first submit to the last msk144_fetch_wait"}
+
+
+def frontend_leg(be, n_steps: int = 5):
+    """Stage time of the front-end kernels alone on the bench's 1024 windows: analytic method 1 (frontend_fft_kernel, the reference's
+    Analytic::execute, analytic_fft.cu:84-157) beside method 2 (frontend_fir_kernel, the default).  The front end does not depend on
+    the search grid, so the two handles are created with a narrow one."""
+    from msk144cudecoder_amd.hipdecoder import HipDecoder
+    out = {}
+    w = be.wins_dev[0]
+    for method, name in ((1, "frontend_fft_kernel"), (2, "frontend_fir_kernel")):
+        with HipDecoder(center=1500.0, width=12.0, step=2.0, depth=1, nbadsync_threshold=0, read_mode=1, analytic_method=method,
+                        channels=w.shape[0], device=be.device.index, max_results=1024) as d:
+            d.set_stream(be.stream.cuda_stream)
+            for _ in range(3):
+                d.submit_audio_device(w.data_ptr())
+            d.synchronize()
+            d.set_profiling(True)
+            d.stage_times(reset=True)
+            for _ in range(n_steps):
+                d.submit_audio_device(w.data_ptr())
+            ms, cnt = d.stage_times()["frontend"]
+            out[name] = {"analytic_method": method, "ms_per_launch": round(ms, 4), "launches": cnt, "channels": int(w.shape[0]),
+                         "windows_per_s": w.shape[0] / (ms * 1e-3) if ms > 0 else None}
+    out["note"] = "HIP events around the one front-end launch of msk144_submit_audio_device, inputs resident in HBM; method 2 is what the timed region runs"
+    return out
+
+
+def configs4_leg(be, n_steps: int = 3, channels: int = 4096):
+    """BASELINE configs[4]: IQ --read-mode=2, 4096 low-SNR synthetic channels (complex AWGN sigma 20 LSB per rail, every 4th channel one ping of
+    3-6 frames at -6..-2 dB), width 500 / step 1 / depth 6 / threshold 3 - the LDPC-iteration-heavy stress - as a short leg on its own handle."""
+    import torch
+    from msk144cudecoder_amd import synth
+    from msk144cudecoder_amd.hipdecoder import HipDecoder
+    wins, truth = synth.iq_low_snr_batch(channels, 5)
+    dev = torch.from_numpy(wins).cuda(be.device.index)
+    with HipDecoder(center=0.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, read_mode=2, channels=channels,
+                    device=be.device.index, max_results=1 << 20) as d:
+        d.set_stream(be.stream.cuda_stream)
+        d.submit_iq_device(dev.data_ptr())
+        d.decode()
+        d.synchronize()
+        d.set_profiling(True)
+        d.stage_times(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            d.submit_iq_device(dev.data_ptr())
+            d.decode()
+        d.synchronize()
+        el = time.perf_counter() - t0
+        st = d.stage_times()
+        res = d.results()
+        hit = {int(r["channel"]) for r in res if truth.get(int(r["channel"])) == bytes(r["message"])}
+        return {"workload": f"BASELINE configs[4]: {channels} int8 I/Q channels (--read-mode=2, centre 0 Hz), width=500 step=1 depth=6 nbadsync-threshold=3 "
+                            f"(F={d.F}, {d.K} candidates/window), one window per channel per step",
+                "value": channels * d.K * n_steps / el, "unit": "candidates/s", "steps": n_steps, "warmup": 1, "ms_per_step": el / n_steps * 1e3,
+                "stage_ms": {n: round(st[n][0], 4) for n in be.T_NAMES}, "llr_block_channels": d.params.llr_block_channels or 64,
+                "decodes_last_step": int(len(res)), "pinged_channels": len(truth), "pinged_channels_decoded": len(hit)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,9 +407,15 @@ def parse_args(argv=None):
     ap.add_argument("--channels", type=int, default=CHANNELS_PER_GPU, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--llr-block", type=int, default=0, help="channels per softbits->index->LDPC block (0 = library default; = channels: retain every LLR row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="time budget of the CPU baseline's bounded sample")
+    ap.add_argument("--force-cpu-baseline", action="store_true",
+                    help="TEST HOOK: time the CPU baseline although --backend-module replaces the GPU backend (rehearsal of the N-rank launch on the CPU)")
     ap.add_argument("--sustain-seconds", type=float, default=20.0,
                     help="after the K timed steps, keep running the same step for about this long (untimed inputs unchanged) and report the step time of its "
                          "first / middle / last 50 steps and the shader clock: `value` stays the K-step figure (0 = skip)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short legs a single-GPU run appends after the timed region: value_incl_h2d (pinned host windows), frontend_method1 "
+                         "(FFT front end beside the FIR one) and configs4_iq (BASELINE configs[4])")
     ap.add_argument("--launcher", action="store_true", help="go through the N-rank launcher even for --gpus 1 (exercises the RCCL gather path)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend-module", default=None, help="TEST HOOK: module providing Backend (e.g. tests/stub_backend.py on gloo); the line is then labelled as such")
@@ -332,11 +433,11 @@ def launch_ranks(args, argv) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cpu_file = None
-    if not args.no_cpu_baseline and not args.backend_module:
+    if not args.no_cpu_baseline and (not args.backend_module or args.force_cpu_baseline):
         # The CPU baseline is timed HERE, before any rank exists: nothing else of the job runs on the host cores meanwhile (timed on
         # rank 0 it shared them with the other ranks' start-up).  numpy + the oracle library only - still no GPU API in this process.
         import tempfile
-        cpu = cpu_baseline(make_inputs(0, args.channels)[0])
+        cpu = cpu_baseline(make_inputs(0, args.channels)[0], args.cpu_baseline_seconds)
         cpu["sample"] += "; timed in the launcher parent before the ranks were started"
         fd, cpu_file = tempfile.mkstemp(prefix="msk144_cpu_baseline_", suffix=".json")
         with os.fdopen(fd, "w") as f:
@@ -390,11 +491,11 @@ def run_worker(args) -> int:
     # (a sampler of GPU activity catches it), and the other ranks of a distributed run simply wait for rank 0 at the rendezvous.
     cpu = None
     handed = os.environ.get("MSK144_BENCH_CPU_BASELINE_FILE")
-    if rank == 0 and not args.no_cpu_baseline and Backend is HipBackend:
+    if rank == 0 and not args.no_cpu_baseline and (Backend is HipBackend or args.force_cpu_baseline):
         if handed and os.path.exists(handed):
             cpu = json.load(open(handed))          # bench.py --gpus N: timed by the launcher parent before the ranks existed
         else:
-            cpu = cpu_baseline(make_inputs(0, channels)[0])
+            cpu = cpu_baseline(make_inputs(0, channels)[0], args.cpu_baseline_seconds)
             _INPUTS.clear()                        # the GPU phase stages its own copy; do not keep a second one alive
             if distributed and world > 1:
                 cpu["sample"] += f"; timed while the other {world - 1} rank(s) of the job were starting up (torch import, rendezvous wait) on the same host"
@@ -459,6 +560,13 @@ def run_worker(args) -> int:
         st2 = be.stage_times()      # averages over the timed region AND the sustained leg (profiling stayed on)
         sustained["stage_ms_incl_timed_region"] = {n: round(st2[n][0], 4) for n in be.T_NAMES}
     last = be.results()         # of the last step run (the sustained leg's when there is one): what the last gather must have carried
+    # Short extra legs, single-GPU runs of the product backend only (each on rank 0 would leave the other ranks waiting): after
+    # everything the main line reports has been read, so they cannot disturb it.
+    extra = {}
+    if not args.no_extra_legs and world == 1 and not distributed and Backend is HipBackend:
+        extra["value_incl_h2d"] = pcie_leg(be, max(4, min(args.steps, 10)))
+        extra["frontend_method1"] = frontend_leg(be)
+        extra["configs4_iq"] = configs4_leg(be)
     # Payloads that are not the channel's transmitted message.  The reference algorithm accepts on CRC-13
     # + < 18 hard errors, so at 1.6e7 BP attempts per step a few false positives are expected; they are
     # the oracle's too (tests/test_gpu_full.py), not decoder errors.
@@ -560,6 +668,7 @@ def run_worker(args) -> int:
                              "ms_per_step": gather.mean_ms(), "ms_note": "copy into the send buffer + gather, timed on rank 0 around RecordGather.step"}
         if sustained is not None:
             out["sustained"] = sustained
+        out.update(extra)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

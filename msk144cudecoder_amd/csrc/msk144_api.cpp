@@ -550,6 +550,7 @@ int msk144_frequency(const msk144_handle* h, int32_t block_idx, float* hz)
 int msk144_set_stream(msk144_handle* h, void* hip_stream)
 {
     if(!h) return MSK144_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->params.device));  // every entry that touches the device selects the handle's own first: a caller may hold handles on several
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     harvest_times(h);
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;

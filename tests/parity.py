@@ -25,6 +25,52 @@ TOL_XB_REL = 1e-4
 TOL_LLR = 1e-3
 PERIODIC = {5: 864, 6: 2592}  # pattern_idx -> period of xb(pos)
 
+# Regression guards, tighter than the contractual tolerances above and derived from what the soaks MEASURED on the final kernels
+# (profiles/r02_soak_fuzz.txt, r03_soak_fuzz.txt, r03_production_soak.json, r04_parity_report.json), so that a kernel change that
+# stays inside the contract but moves the numbers is seen:
+#   * max |dLLR| 1.1e-5 over 8000 fuzz cases and the full-size windows  ->  guard 1e-4 * max(1, |llr|), a tenth of the contract
+#   * verified scan near-ties: 82 in 15.39 M slots (production soak), 11 in 2.48 M, 1 in 0.81 M  ->  5.3e-6 per slot
+#   * verified nbadsync marginals: 8 in 15.39 M candidates                                       ->  5.2e-7 per candidate
+#   * verified marginal BP decisions: 0 in 2.27 M decodes (rule of three: < 1.3e-6)              ->  1.3e-6 per decode
+#   * periodic-pattern groups that do not even agree modulo the period (fall back to the near-tie rule): 0 ever seen; counted with
+#     the near-ties
+# A test's limit is the count a Poisson variable with THREE times the measured rate exceeds with probability < 1e-3 (count_limit):
+# the deep window (24 048 slots) may show 3 near-ties, 1 nbadsync marginal, 2 marginal BP decisions - observed 0 / 0 / 0 - where
+# the round-4 limits were 24 / 8 / 4.  The rates are those of HIP kernels against the oracle; comparisons of another kind (the oracle's
+# FMA-contracting builds against its parity build, tests/test_oracle_fma_bracket.py) pass enforce_limits=False and keep their own asserts.
+TOL_LLR_REGRESSION = 1e-4
+NEAR_TIE_RATE = 5.3e-6
+NBADSYNC_MARGINAL_RATE = 5.2e-7
+BP_MARGINAL_RATE = 1.3e-6
+
+
+def count_limit(rate: float, n: int, factor: float = 3.0, p_false_alarm: float = 1e-3) -> int:
+    """Smallest k with P(X > k) < p_false_alarm for X ~ Poisson(factor * rate * n)."""
+    import math
+    lam = factor * rate * max(int(n), 0)
+    if lam > 30.0:  # normal tail (exp(-lam) underflows long before the sum would matter): P(Z > 3.3) < 5e-4
+        return int(lam + 3.3 * math.sqrt(lam)) + 1
+    term = math.exp(-lam)
+    cdf = term
+    k = 0
+    while 1.0 - cdf >= p_false_alarm:
+        k += 1
+        term *= lam / k
+        cdf += term
+    return k
+
+
+def near_tie_limit(slots: int) -> int:
+    return count_limit(NEAR_TIE_RATE, slots)
+
+
+def nbadsync_marginal_limit(candidates: int) -> int:
+    return count_limit(NBADSYNC_MARGINAL_RATE, candidates)
+
+
+def bp_marginal_limit(decodes: int) -> int:
+    return count_limit(BP_MARGINAL_RATE, decodes)
+
 
 def llr_close(a, b):
     a = np.asarray(a, dtype=np.float64)
@@ -32,14 +78,17 @@ def llr_close(a, b):
     return np.abs(a - b) <= TOL_LLR * np.maximum(1.0, np.abs(a))
 
 
-def compare_scan(o, cd, items_o, items_g):
-    """Returns dict(exact, near_ties, periodic_groups).  Raises AssertionError on a real mismatch."""
+def compare_scan(o, cd, items_o, items_g, near_tie_factor: float = 1.0, enforce_limits: bool = True):
+    """Returns dict(exact, near_ties, periodic_groups, periodic_fallbacks, near_tie_limit).  Raises AssertionError on a real mismatch,
+    and when the verified near-ties (plus periodic groups that needed the near-tie rule) exceed the measured-rate limit for this many
+    slots (near_tie_factor widens it for inputs with fewer significant bits, e.g. denormals)."""
     D = o.D
     n = len(items_o)
     assert len(items_g) == n
     exact = 0
     near = 0
     groups = 0
+    fallbacks = 0
     xb_cache = {}
 
     def xb_all(b, p):
@@ -67,7 +116,10 @@ def compare_scan(o, cd, items_o, items_g):
         assert np.all(np.abs(ref[pg] - xg) <= TOL_XB_REL * scale), (b, p, pg, xg, ref[pg])
         if p in PERIODIC:
             per = PERIODIC[p]
-            assert sorted((po % per).tolist()) == sorted((pg % per).tolist()) or _near_tie_sets(ref, po, pg, scale), (b, p, po, pg)
+            if sorted((po % per).tolist()) != sorted((pg % per).tolist()):
+                # not even the same positions modulo the period: only acceptable as an ordinary verified near-tie, and counted as one
+                assert _near_tie_sets(ref, po, pg, scale), (b, p, po, pg)
+                fallbacks += 1
             groups += 1
         else:
             # a differing slot is acceptable only when the oracle itself sees a near-tie between the
@@ -75,7 +127,10 @@ def compare_scan(o, cd, items_o, items_g):
             assert _near_tie_sets(ref, po, pg, scale), (b, p, po, pg, xo, xg)
             near += int((po != pg).sum())
             exact += int((po == pg).sum())
-    return dict(exact=exact, near_ties=near, periodic_groups=groups, total=n)
+    limit = count_limit(NEAR_TIE_RATE * near_tie_factor, n)
+    rep = dict(exact=exact, near_ties=near, periodic_groups=groups, periodic_fallbacks=fallbacks, near_tie_limit=limit, total=n)
+    assert not enforce_limits or near + fallbacks <= limit, ("more verified near-ties than three times the measured rate allows", rep)
+    return rep
 
 
 def _near_tie_sets(ref, po, pg, scale):
@@ -99,13 +154,17 @@ def expected_softbits(o, cd, items_o, items_g):
     return exp_llr, exp_nb
 
 
-def compare_softbits(o, cd, items_o, items_g):
+def compare_softbits(o, cd, items_o, items_g, enforce_limits: bool = True):
     exp_llr, exp_nb = expected_softbits(o, cd, items_o, items_g)
     got = items_g["softbits_wo_sync"]
     finite = np.isfinite(exp_llr).all(axis=1)
     ok = llr_close(exp_llr[finite], got[finite])
     bad_rows = np.nonzero(~ok.all(axis=1))[0]
     assert len(bad_rows) == 0, ("LLR out of tolerance", bad_rows[:5], np.abs(exp_llr[finite] - got[finite]).max())
+    # regression guard (not the contract): ten times what the soaks measured, a tenth of the contract
+    e64, g64 = exp_llr[finite].astype(np.float64), got[finite].astype(np.float64)
+    worst_rel = float((np.abs(e64 - g64) / np.maximum(1.0, np.abs(e64))).max()) if finite.any() else 0.0
+    assert not enforce_limits or worst_rel <= TOL_LLR_REGRESSION, ("LLRs inside the 1e-3 contract but beyond the 1e-4 regression guard (measured: 1.1e-5)", worst_rel)
     # nbadsync: exact, unless a sync softbit of that candidate is within tolerance of zero
     nb_diff = np.nonzero(exp_nb != items_g["nbadsync"])[0]
     marginal = 0
@@ -115,7 +174,11 @@ def compare_softbits(o, cd, items_o, items_g):
         rms = float(np.sqrt(np.mean(np.square(soft))))
         assert np.min(np.abs(sync)) <= 1e-3 * rms, ("nbadsync differs without a marginal sync softbit", k, exp_nb[k], items_g["nbadsync"][k])
         marginal += 1
-    return dict(llr_max_abs_diff=float(np.abs(exp_llr[finite] - got[finite]).max()) if finite.any() else 0.0, nbadsync_marginal=marginal)
+    limit = nbadsync_marginal_limit(len(items_g))
+    rep = dict(llr_max_abs_diff=float(np.abs(exp_llr[finite] - got[finite]).max()) if finite.any() else 0.0, llr_max_rel_diff=worst_rel,
+               nbadsync_marginal=marginal, nbadsync_marginal_limit=limit)
+    assert not enforce_limits or marginal <= limit, ("more verified nbadsync marginals than three times the measured rate allows", rep)
+    return rep
 
 
 BP_PERTURBATION_SCALES = (1e-6, 1e-5, 1e-4)   # relative LLR perturbations, all far inside the stated LLR tolerance (1e-3)
@@ -169,10 +232,12 @@ def compare_ldpc_against_oracle_on_gpu_llrs(orc_mod, items_g, threshold):
             continue
         scale = verify_marginal_bp(orc_mod, llr, (g_ok, g_it), seed=1000 + k)
         flips.append(dict(item=int(k), oracle=[ok, it], gpu=[g_ok, g_it], unstable_at_relative_perturbation=scale))
-    return dict(checked=checked, marginal_flips=len(flips), flips=flips)
+    rep = dict(checked=checked, marginal_flips=len(flips), marginal_limit=bp_marginal_limit(checked), flips=flips)
+    assert len(flips) <= rep["marginal_limit"], ("more verified marginal BP decisions than three times the measured bound allows", rep)
+    return rep
 
 
-def compare_ldpc_items(orc_mod, items_o, items_g, same):
+def compare_ldpc_items(orc_mod, items_o, items_g, same, enforce_limits: bool = True):
     """Full-window form: items_o are the oracle's results on the oracle's own LLRs; for every candidate in `same` (identical
     position and nbadsync) accept/iteration/hard errors/payload must be identical, except verified-marginal cases (the LLRs
     themselves differ by <= 1e-3 there, so the perturbation test is run around the GPU's LLRs with the oracle's outcome as the
@@ -197,7 +262,9 @@ def compare_ldpc_items(orc_mod, items_o, items_g, same):
     both = same & (items_o["is_message_present"] == 1) & (items_g["is_message_present"] == 1)
     assert np.array_equal(items_o["message"][both], items_g["message"][both])
     assert np.array_equal(items_o["ldpc_num_hard_errors"][both], items_g["ldpc_num_hard_errors"][both])
-    return dict(compared=int(same.sum()), both_accepted=int(both.sum()), marginal_flips=len(flips), flips=flips)
+    rep = dict(compared=int(same.sum()), both_accepted=int(both.sum()), marginal_flips=len(flips), marginal_limit=bp_marginal_limit(int(same.sum())), flips=flips)
+    assert not enforce_limits or len(flips) <= rep["marginal_limit"], ("more verified marginal BP decisions than three times the measured bound allows", rep)
+    return rep
 
 
 def decoded_set(items):

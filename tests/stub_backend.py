@@ -20,7 +20,15 @@ class Backend:
         self.cand_per_step = channels * self.K
         self.channel_base = channel_base
         self.truth = {}
-        self.wins_host = np.zeros((1, channels, 5184), dtype=np.int16)
+        import os
+        if os.environ.get("MSK144_STUB_REAL_INPUTS"):
+            # rehearsal of the real ranks' start-up cost on the CPU: every rank synthesises its own 1024-channel input set, as
+            # bench.HipBackend does before it stages it in HBM
+            import bench
+            self.wins_host, self.truth = bench.make_inputs(rank, channels)
+            self.truth = {}
+        else:
+            self.wins_host = np.zeros((1, channels, 5184), dtype=np.int16)
         n = min(channels, 5 + rank)
         rec = np.zeros(n, dtype=RESULT_DTYPE)
         rec["channel"] = channel_base + np.arange(n)

@@ -10,11 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None, timeout=300):
+def _run(extra, env_extra=None, timeout=300, channels=8):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--channels", "8", "--sustain-seconds", "0.2",
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--channels", str(channels), "--sustain-seconds", "0.2",
                            "--backend-module", "stub_backend"] + extra, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
@@ -52,6 +52,31 @@ def test_gpus8_self_launch_on_gloo():
     g = out["gather"]
     assert g["peak_records_per_rank"] == [5, 6, 7, 8, 8, 8, 8, 8] and g["records_last_step"] == 58      # min(channels, 5 + rank) records per rank
     assert len(out["rank_ms_per_step"]["per_rank"]) == 8
+
+
+def test_gpus8_rehearsal_full_size_inputs_and_cpu_baseline():
+    """First-time-right check for the driver's `python bench.py --gpus 8` (no 8-GPU node has run it yet): the
+    logistics of the real launch on the CPU - the launcher parent times the CPU baseline before any rank exists, eight ranks start
+    through torch.distributed.run, EVERY rank synthesises its full 1024-channel input set (bench.make_inputs, what HipBackend stages),
+    the per-step gather runs on gloo - and the one line carries everything the driver's record needs.  The wall clock of this
+    rehearsal (8 host cores here, 16 on a GPU box's quota) is the host-side floor of the real run's driver_run_s; DESIGN 6 states it."""
+    import time
+    t0 = time.monotonic()
+    p = _run(["--gpus", "8", "--force-cpu-baseline", "--cpu-baseline-seconds", "3"], env_extra={"MSK144_STUB_REAL_INPUTS": "1"}, timeout=900, channels=1024)
+    wall = time.monotonic() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["channels_per_gpu"] == 1024 and out["config"]["parallelism"] == "channel-shard x8"
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel"] and out["roofline"]["launches_per_step"] >= 1
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and "launcher parent" in cpu["sample"]
+    assert len(out["rank_ms_per_step"]["per_rank"]) == 8 and len(out["gather"]["peak_records_per_rank"]) == 8
+    assert out["gather"]["capacity_per_rank"] == 32 * 1024 and out["gather"]["records_last_step"] == sum(5 + r for r in range(8))
+    assert "sustained" in out and out["sustained"]["steps"] >= 150
+    assert wall < 600, wall
+    print(f"8-rank rehearsal wall clock: {wall:.1f} s")
 
 
 def test_gpus1_through_launcher_matches_contract():

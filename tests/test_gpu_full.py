@@ -26,15 +26,16 @@ def test_deep_window_against_oracle(orc, hip, parity_report):
         items_g = d.dump_candidates(0)
         idx_g = d.dump_indexes(0)
     rep = parity.compare_scan(o, cd, items_o, items_g)
-    assert rep["near_ties"] <= 24, rep                       # <= 0.1 % of slots decided inside the tolerance
+    assert rep["near_ties"] + rep["periodic_fallbacks"] <= parity.near_tie_limit(24048) == 3, rep   # measured-rate limit (parity.py); observed 0
     sb = parity.compare_softbits(o, cd, items_o, items_g)
-    assert sb["nbadsync_marginal"] <= 8, sb
+    assert sb["nbadsync_marginal"] <= parity.nbadsync_marginal_limit(24048) == 1, sb
+    assert sb["llr_max_rel_diff"] <= parity.TOL_LLR_REGRESSION
     assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= 3)[0])
     same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
     # accept / iterations / hard errors / payload identical wherever the candidate itself is identical; any difference
     # must be a VERIFIED marginal case (oracle decision unstable under 1e-6..1e-4 LLR perturbations)
     ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
-    assert ld["marginal_flips"] <= 4, ld
+    assert ld["marginal_flips"] <= parity.bp_marginal_limit(24048) == 2, ld
     assert ld["both_accepted"] > 10
     parity_report("deep_window_F501_D6", dict(scan=rep, softbits=sb, ldpc=ld))
     assert bytes(msg) in parity.decoded_messages(items_g)
@@ -117,11 +118,11 @@ def test_fine_step_depth8_all_gated(orc, hip, parity_report):
     assert np.array_equal(idx_g, np.arange(25664)) and np.array_equal(idx_o, idx_g)
     assert np.array_equal(items_o["f0"].view(np.uint32), items_g["f0"].view(np.uint32))
     rep = parity.compare_scan(o, cd, items_o, items_g)
-    assert rep["near_ties"] <= 26, rep
+    assert rep["near_ties"] + rep["periodic_fallbacks"] <= parity.near_tie_limit(25664) == 3, rep
     parity.compare_softbits(o, cd, items_o, items_g)
     same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
     ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
-    assert ld["marginal_flips"] <= 4, ld
+    assert ld["marginal_flips"] <= parity.bp_marginal_limit(25664), ld
     parity_report("fine_step_depth8_all_gated", dict(scan=rep, ldpc=ld))
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
     assert bytes(msg) in parity.decoded_messages(items_g)
@@ -240,12 +241,12 @@ def test_maximum_grid_single_channel(orc, hip, parity_report):
         res = d.results()
     assert np.array_equal(items_o["f0"].view(np.uint32), items_g["f0"].view(np.uint32))
     rep = parity.compare_scan(o, cd, items_o, items_g)
-    assert rep["near_ties"] <= 128, rep
+    assert rep["near_ties"] + rep["periodic_fallbacks"] <= parity.near_tie_limit(128064) == 8, rep       # 0.68 expected at the measured rate; observed 0
     sb = parity.compare_softbits(o, cd, items_o, items_g)
     assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= 4)[0])
     same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
     ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
-    assert ld["marginal_flips"] <= 4, ld
+    assert ld["marginal_flips"] <= parity.bp_marginal_limit(128064), ld
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
     assert {bytes(m1), bytes(m2)} <= parity.decoded_messages(items_g)
     assert np.array_equal(res["item"], np.nonzero(items_g["is_message_present"])[0])

@@ -113,9 +113,9 @@ def test_stages_against_oracle(orc, hip, parity_report, ci, seed):
 
     rep = parity.compare_scan(o, cd, items_o, items_g)
     # outside the two periodic patterns positions must match exactly up to verified near-ties
-    assert rep["near_ties"] <= max(2, rep["total"] // 100), rep
+    assert rep["near_ties"] + rep["periodic_fallbacks"] <= rep["near_tie_limit"] <= 1, rep     # a few hundred slots: at most one, at the measured rate
     sb = parity.compare_softbits(o, cd, items_o, items_g)
-    assert sb["nbadsync_marginal"] <= 2, sb
+    assert sb["nbadsync_marginal"] <= sb["nbadsync_marginal_limit"] <= 1, sb
 
     # index list: exactly the ascending list of items with nbadsync <= threshold (of the GPU's own nbadsync)
     exp_idx = np.nonzero(items_g["nbadsync"] <= cfg["nbadsync_threshold"])[0].astype(np.int32)
@@ -124,7 +124,7 @@ def test_stages_against_oracle(orc, hip, parity_report, ci, seed):
         assert np.array_equal(idx_g, idx_o)
 
     ld = parity.compare_ldpc_against_oracle_on_gpu_llrs(orc, items_g, cfg["nbadsync_threshold"])
-    assert ld["marginal_flips"] <= 2, ld          # each one verified unstable by parity.verify_marginal_bp
+    assert ld["marginal_flips"] <= ld["marginal_limit"] <= 1, ld          # each one verified unstable by parity.verify_marginal_bp
     parity_report(f"stages_cfg{ci}_seed{seed}", dict(scan=rep, softbits=sb, ldpc=ld))
 
     # decoded payloads: same set of messages as the oracle, and it is the transmitted one
@@ -296,6 +296,52 @@ def test_fft_frontend_end_to_end(orc, hip):
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o) == {bytes(msg)}
 
 
+def test_fft_frontend_1024_channel_batch(orc, hip, parity_report):
+    """--analytic-method=1 at the bench's batch size (analytic_fft.cu:84-157, one workgroup per channel): 1024 windows in one launch.
+    (1) batch == single: a channel's analytic window and segment powers are bit-for-bit what a one-channel handle computes for
+    the same samples; (2) every sampled channel within 1e-5 of the window rms of the oracle's FFT front end; (3) end to end: the
+    payload set of every pinged sample channel equals the oracle's, stage by stage on the GPU's own analytic window."""
+    n_ch = 1024
+    cfg = dict(center=1500.0, width=12.0, step=2.0, depth=4, nbadsync_threshold=1)
+    rng = np.random.default_rng(4242)
+    wins = np.rint(rng.normal(0.0, 1000.0, size=(n_ch, 5184))).astype(np.int16)
+    pinged = list(range(0, n_ch, 64))
+    msgs = {}
+    for c in pinged:
+        w, m = _audio_window(7000 + c, snr=5.0, n_frames=5, freq=1498.0 + (c // 64) % 5, start=100 + 7 * (c // 64))
+        wins[c] = w
+        msgs[c] = m
+    wins[5] = 0                                   # a muted channel in the batch: 1/0 normalisation, NaNs stay in their own channel
+    sample = pinged + [1, 2, 3, 4, 6, 511, 1023]
+    o = orc.Oracle(threads=8, **cfg)
+    worst = 0.0
+    with hip.HipDecoder(analytic_method=1, channels=n_ch, llr_block_channels=n_ch, **cfg) as d:
+        d.submit_audio(wins)
+        d.decode()
+        seg = d.segment_power()
+        batch = {c: d.dump_analytic(c) for c in sample + [5]}
+        items = {c: d.dump_candidates(c) for c in pinged}
+    assert not np.isfinite(batch[5]).any()
+    with hip.HipDecoder(analytic_method=1, channels=1, **cfg) as d1:
+        for c in sample:
+            d1.submit_audio(wins[c])
+            assert np.array_equal(d1.dump_analytic(0).view(np.uint32), batch[c].view(np.uint32)), c      # (1)
+            assert np.array_equal(d1.segment_power()[0].view(np.uint32), seg[c].view(np.uint32)), c
+    for c in sample:
+        exp = o.frontend_audio(wins[c], 1)
+        rms = np.sqrt(np.mean(np.abs(exp) ** 2))
+        err = float(np.abs(batch[c] - exp).max() / rms)
+        worst = max(worst, err)
+        assert err <= 1e-5, (c, err)                                                                      # (2)
+    for c in pinged:
+        items_o, _ = o.decode_window(batch[c])
+        parity.compare_scan(o, batch[c], items_o, items[c])
+        parity.compare_softbits(o, batch[c], items_o, items[c])
+        assert parity.decoded_messages(items[c]) == parity.decoded_messages(items_o) == {bytes(msgs[c])}, c   # (3)
+    parity_report("fft_frontend_1024_channels", dict(channels=n_ch, sampled=len(sample), max_err_over_rms=worst, tolerance=1e-5, batch_equals_single=True,
+                                                     pinged_channels_decoded=len(pinged)))
+
+
 def test_iq_batch_low_snr(orc, hip):
     """configs[4] shape at reduced size: IQ, low SNR, threshold 3; every channel equals its oracle decode set."""
     cfg = dict(center=0.0, width=24.0, step=1.0, depth=6, nbadsync_threshold=3)
@@ -349,6 +395,6 @@ def test_scan_tiny_amplitude_window(orc, hip, parity_report):
         d.decode(hip.STAGE_SCAN)
         items_g = d.dump_candidates(0)
     assert np.all(items_g["xb"] > 0) and np.all(np.isfinite(items_g["xb"]))
-    rep = parity.compare_scan(o, cd, items_o, items_g)
-    assert rep["near_ties"] <= max(4, rep["total"] // 50), rep                  # denormals carry fewer bits: a few more verified near-ties
+    rep = parity.compare_scan(o, cd, items_o, items_g, near_tie_factor=100.0)    # denormals carry fewer bits: the near-tie rate of full-precision windows does not apply
+    assert rep["near_ties"] + rep["periodic_fallbacks"] <= rep["near_tie_limit"] <= 4, rep
     parity_report("scan_tiny_amplitude", rep)

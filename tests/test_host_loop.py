@@ -153,6 +153,8 @@ def test_many_streams_unpaced_through_the_scale_harness(exe):
     try:
         res = host_scale.run(256, 12, pace_ms=0.0, timeout_s=60.0)
         two = host_scale.run(128, 6, pace_ms=20.0, timeout_s=60.0, devices="0,1", phase_spread_ms=15.0)
+        # every stream on its own hop clock, 40 hops fed out of 5 hops of synthesised signal (the long-run mode of the harness)
+        own = host_scale.run(64, 40, pace_ms=20.0, timeout_s=60.0, phase_spread_ms=20.0, phase_per_stream=True, phase_seed=3, loop_hops=5)
     finally:
         del os.environ["MSK144_STUB_DEVICES"]
         host_scale.EXE = old
@@ -164,6 +166,8 @@ def test_many_streams_unpaced_through_the_scale_harness(exe):
     assert two["returncode"] == 0 and two["stream_hops"] == 128 * 7 and len(two["per_device"]) == 2, two
     assert [d["streams"] for d in two["per_device"]] == [64, 64] and two["per_device"][1]["first_stream"] == 64
     assert all("ingest (read syscalls, all streams)" in d["host_ms_per_batch"] for d in two["per_device"])
+    assert own["returncode"] == 0 and own["feeder_errors"] == 0 and own["stream_hops"] == 64 * 41, own
+    assert own["phases"].startswith("one per stream") and "looped_signal" in own and own["margin_ms_to_210"] == 210 - own["worst_latency_ms"]
 
 
 def _feed_fifos(paths, data, chunk=5184):

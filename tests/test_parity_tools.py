@@ -46,3 +46,21 @@ def test_identical_items_report_no_flips(orc):
     items["ldpc_num_iterations"][0] += 2                              # a wrong iteration count on a stable case
     with pytest.raises(AssertionError, match="STABLE"):
         parity.compare_ldpc_against_oracle_on_gpu_llrs(orc, items, threshold=3)
+
+
+def test_count_limits_follow_the_measured_rates():
+    """The regression limits the GPU comparators enforce (tests/parity.py): Poisson quantiles at three times the measured rates."""
+    assert parity.near_tie_limit(24048) == 3 and parity.nbadsync_marginal_limit(24048) == 1 and parity.bp_marginal_limit(24048) == 2    # the deep window
+    assert parity.near_tie_limit(40) == 0 and parity.near_tie_limit(528) == 1 and parity.near_tie_limit(128064) == 8
+    assert parity.count_limit(1e-6, 0) == 0
+    # monotone in the number of slots, and the false-alarm probability at the limit is below 1e-3
+    import math
+    last = 0
+    for n in (10, 100, 1000, 10 ** 4, 10 ** 5, 10 ** 6):
+        k = parity.near_tie_limit(n)
+        assert k >= last
+        last = k
+        lam = 3.0 * parity.NEAR_TIE_RATE * n
+        assert 1.0 - sum(math.exp(-lam) * lam ** i / math.factorial(i) for i in range(k + 1)) < 1e-3
+    assert parity.near_tie_limit(10 ** 9) > parity.near_tie_limit(10 ** 8) > parity.near_tie_limit(10 ** 7) >= last      # normal-tail branch
+    assert parity.TOL_LLR_REGRESSION * 10 == pytest.approx(parity.TOL_LLR)

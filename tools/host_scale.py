@@ -66,15 +66,19 @@ def parse_timing(err: str):
 
 
 def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feeders: int = 8, hop_timeout_ms: int = None, timeout_s: float = 180.0, devices: str = None,
-        phase_spread_ms: float = 0.0, keep_lines=()):
+        phase_spread_ms: float = 0.0, keep_lines=(), phase_per_stream: bool = False, phase_seed: int = 11, loop_hops: int = 0):
     """devices: value for --devices (e.g. "0,0" or "0,1,2,3"): one ingest+post thread pair per entry, per-device rows in the result.
-    phase_spread_ms: every feeder thread's hop clock is offset by a fixed random phase in [0, phase_spread_ms) - streams that are NOT
-    phase-aligned (real receivers are not), instead of all hops falling due together."""
+    phase_spread_ms: hop clocks offset by a fixed random phase in [0, phase_spread_ms) - streams that are NOT phase-aligned (real
+    receivers are not), instead of all hops falling due together; one phase per feeder thread, or (phase_per_stream) one per STREAM,
+    drawn with phase_seed.  loop_hops > 0: only that many hops of signal are synthesised per stream and fed round and round, so that a
+    run of minutes (n_hops in the hundreds) does not need gigabytes of samples; the decode statistics of such a run are not meaningful,
+    its timing is."""
     import resource
     soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
     if soft < n_streams + 256:
         resource.setrlimit(resource.RLIMIT_NOFILE, (min(hard, n_streams + 256) if hard != resource.RLIM_INFINITY else n_streams + 256, hard))
-    streams, sent = make_streams(n_streams, n_hops)
+    base_hops = min(n_hops, loop_hops) if loop_hops > 0 else n_hops
+    streams, sent = make_streams(n_streams, base_hops)
     tmp = tempfile.mkdtemp(prefix="msk144_fifos_")
     paths = [os.path.join(tmp, f"s{c:05d}.fifo") for c in range(n_streams)]
     for p in paths:
@@ -110,18 +114,33 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
         t0 = time.monotonic()
         start = threading.Barrier(feeders)
 
-        phases = np.random.default_rng(11).uniform(0.0, phase_spread_ms * 1e-3, size=feeders) if phase_spread_ms > 0 else np.zeros(feeders)
+        prng = np.random.default_rng(phase_seed)
+        phases = prng.uniform(0.0, phase_spread_ms * 1e-3, size=feeders) if phase_spread_ms > 0 else np.zeros(feeders)
+        stream_phase = prng.uniform(0.0, phase_spread_ms * 1e-3, size=n_streams) if (phase_spread_ms > 0 and phase_per_stream) else None
 
         def feed(lo, hi):
             try:
                 start.wait()
+                if stream_phase is not None:
+                    # every stream on its own hop clock: the feeder walks its streams in phase order, hop after hop
+                    order = sorted(range(lo, hi), key=lambda c: stream_phase[c])
+                    for h in range(-1, n_hops):
+                        hh = h % base_hops
+                        a, b = (0, 5184 * 2) if h < 0 else (5184 * 2 + hh * 5184, 5184 * 2 + (hh + 1) * 5184)
+                        for c in order:
+                            dt = t0 + 0.5 + float(stream_phase[c]) + pace_ms * 1e-3 * (h + 1) - time.monotonic()
+                            if dt > 0 and pace_ms > 0:
+                                time.sleep(dt)
+                            os.write(fds[c], raw[c, a:b].tobytes())
+                    return
                 phase = float(phases[lo // per])
                 if phase > 0:
                     time.sleep(phase)
                 for h in range(-1, n_hops):
                     if h >= 0 and pace_ms > 0:
                         time.sleep(max(0.0, t0 + 0.5 + phase + pace_ms * 1e-3 * (h + 1) - time.monotonic()))
-                    a, b = (0, 5184 * 2) if h < 0 else (5184 * 2 + h * 5184, 5184 * 2 + (h + 1) * 5184)
+                    hh = h % base_hops
+                    a, b = (0, 5184 * 2) if h < 0 else (5184 * 2 + hh * 5184, 5184 * 2 + (hh + 1) * 5184)
                     for c in range(lo, hi):
                         os.write(fds[c], raw[c, a:b].tobytes())
             except OSError as e:
@@ -176,6 +195,12 @@ def run(n_streams: int, n_hops: int, pace_ms: float = 216.0, extra_args=(), feed
         if dev:
             res["device_ms_per_batch"] = dev
     res["phase_spread_ms"] = phase_spread_ms
+    res["phases"] = ("one per stream" if phase_per_stream else "one per feeder thread") + f", seed {phase_seed}" if phase_spread_ms > 0 else "aligned"
+    res["signal_seconds"] = round((n_hops + 1) * pace_ms * 1e-3, 1)
+    if loop_hops > 0 and base_hops < n_hops:
+        res["looped_signal"] = f"{base_hops} hops of synthesised signal per stream, fed cyclically (timing run: decode statistics not meaningful)"
+    if "worst_latency_ms" in res:
+        res["margin_ms_to_210"] = 210 - res["worst_latency_ms"]
     decoded = {}
     for ch, bits in re.findall(r"ch=(\d+); .*?bits='([01]{77})'", out):
         decoded.setdefault(int(ch), set()).add(bits)
@@ -203,8 +228,12 @@ def main():
     ap.add_argument("--devices", default=None, help="passed to the decoder as --devices=... (one loop per entry; an ordinal may repeat)")
     ap.add_argument("--phase-spread-ms", type=float, default=0.0, help="spread the feeders' hop clocks over this many ms instead of phase-aligning every stream")
     ap.add_argument("--feeders", type=int, default=8)
+    ap.add_argument("--phase-per-stream", action="store_true", help="with --phase-spread-ms: one random phase per STREAM instead of one per feeder thread")
+    ap.add_argument("--phase-seed", type=int, default=11)
+    ap.add_argument("--loop-hops", type=int, default=0, help="synthesise only this many hops per stream and feed them cyclically (long timing runs)")
     a = ap.parse_args()
-    print(json.dumps(run(a.streams, a.hops, a.pace_ms, hop_timeout_ms=a.hop_timeout_ms, devices=a.devices, phase_spread_ms=a.phase_spread_ms, feeders=a.feeders)), flush=True)
+    print(json.dumps(run(a.streams, a.hops, a.pace_ms, hop_timeout_ms=a.hop_timeout_ms, devices=a.devices, phase_spread_ms=a.phase_spread_ms, feeders=a.feeders,
+                         phase_per_stream=a.phase_per_stream, phase_seed=a.phase_seed, loop_hops=a.loop_hops, timeout_s=300.0)), flush=True)
 
 
 if __name__ == "__main__":
