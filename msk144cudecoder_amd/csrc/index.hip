@@ -42,6 +42,24 @@ __device__ __forceinline__ int ordered_slot(bool flag, int& base, int* s_wave_co
     return slot;
 }
 
+// index_kernel.cuh:30-50: a candidate goes to the LDPC when its sync words disagree in at most `threshold` bits.  A negative
+// value is not a count: softbits_kernel<true> stores -1 - s for a candidate of a periodic pattern (masks 111111, 100100) whose
+// folded frames are those of slot s < its own of the same (frequency, pattern) group - that slot is decoded, this one takes its
+// result in the collect stage (source_item below).
+__device__ __forceinline__ bool passes_gate(int32_t nbad, int32_t threshold)
+{
+    return nbad >= 0 && nbad <= threshold;
+}
+
+static_assert((kSlotsPerPattern & (kSlotsPerPattern - 1)) == 0, "a group's first item is k with the slot bits cleared");
+
+// the item whose nbadsync and decode item k reports: itself, or the lower slot of its group it was handed to
+__device__ __forceinline__ int source_item(const int32_t* __restrict__ nbad, int k)
+{
+    const int nb = nbad[k];
+    return nb < 0 ? (k & ~(kSlotsPerPattern - 1)) + (-1 - nb) : k;
+}
+
 __global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st)
 {
     __shared__ int s_wave_count[kIdxWaves];
@@ -74,7 +92,7 @@ __global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st
         {
             const int k = k0 + j * 64 + lane;
             if(k < k_end) st.dec_flag[off + k] = 0;  // clear_result (result_keeper.cuh:61-73) for the fields LDPC may set
-            count += __popcll(__ballot(nb[j] <= st.nbadsync_threshold));
+            count += __popcll(__ballot(passes_gate(nb[j], st.nbadsync_threshold)));
         }
     }
     if(lane == 0) s_wave_count[wave] = count;
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st
         for(int j = 0; j < kBatch; j++)
         {
             const int k = k0 + j * 64 + lane;
-            const bool flag = nb[j] <= st.nbadsync_threshold;
+            const bool flag = passes_gate(nb[j], st.nbadsync_threshold);
             const unsigned long long m = __ballot(flag);
             if(flag) out[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
             base += __popcll(m);
@@ -115,8 +133,9 @@ __global__ __launch_bounds__(kIdxThreads) void collect_count_kernel(const Device
     __shared__ int s_wave_count[kIdxWaves];
     const int ch = blockIdx.x;
     const size_t off = static_cast<size_t>(ch) * st.K;
+    const int32_t* __restrict__ nbad = st.nbadsync + off;
     int cnt = 0;
-    for(int k = threadIdx.x; k < st.K; k += kIdxThreads) cnt += st.dec_flag[off + k] ? 1 : 0;
+    for(int k = threadIdx.x; k < st.K; k += kIdxThreads) cnt += st.dec_flag[off + source_item(nbad, k)] ? 1 : 0;
     // wave reduce
     for(int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
     if((threadIdx.x & 63) == 0) s_wave_count[threadIdx.x >> 6] = cnt;
@@ -154,11 +173,13 @@ __global__ __launch_bounds__(kIdxThreads) void collect_scatter_kernel(const Devi
     __syncthreads();
 
     msk144_result* __restrict__ out = static_cast<msk144_result*>(st.results);
+    const int32_t* __restrict__ nbad = st.nbadsync + off;
     const int per_freq = st.D * kSlotsPerPattern;
     for(int k0 = 0; k0 < st.K; k0 += kIdxThreads)
     {
         const int k = k0 + threadIdx.x;
-        const bool flag = (k < st.K) && st.dec_flag[off + k];
+        const int src = k < st.K ? source_item(nbad, k) : 0;  // where this slot's nbadsync and decode come from (itself, but for handed-over copies)
+        const bool flag = (k < st.K) && st.dec_flag[off + src];
         const int slot = ordered_slot(flag, base, s_wave_count);
         if(slot >= 0 && slot < st.max_results)
         {
@@ -172,10 +193,10 @@ __global__ __launch_bounds__(kIdxThreads) void collect_scatter_kernel(const Devi
             r.num_avg = kPatternNumAvg[p];
             r.pos = st.pos[off + k];
             r.xb = st.xb[off + k];
-            r.nbadsync = st.nbadsync[off + k];
-            r.ldpc_iterations = st.dec_iter[off + k];
-            r.ldpc_hard_errors = st.dec_nhard[off + k];
-            const uint32_t* w = st.dec_msg + (off + k) * 3;
+            r.nbadsync = nbad[src];
+            r.ldpc_iterations = st.dec_iter[off + src];
+            r.ldpc_hard_errors = st.dec_nhard[off + src];
+            const uint32_t* w = st.dec_msg + (off + src) * 3;
             const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
             r.message[0] = w0 >> 24; r.message[1] = w0 >> 16; r.message[2] = w0 >> 8; r.message[3] = w0;
             r.message[4] = w1 >> 24; r.message[5] = w1 >> 16; r.message[6] = w1 >> 8; r.message[7] = w1;

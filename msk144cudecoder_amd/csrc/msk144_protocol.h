@@ -50,6 +50,10 @@ constexpr uint8_t kPatternMask[kScanDepthMax][kPatternBits] = {
     {1, 1, 1, 1, 1, 0}, {1, 1, 1, 1, 1, 1}, {1, 0, 0, 1, 0, 0}, {1, 0, 0, 1, 1, 0},
 };
 constexpr int kPatternNumAvg[kScanDepthMax] = {1, 2, 3, 4, 5, 6, 2, 3};
+// Patterns 5 (111111) and 6 (100100) sum the same frames at pos and at pos + 864 (pattern 5) / pos + 2592 (pattern 6): their
+// correlation and their folded frame are periodic in the position.
+constexpr int kFirstPeriodicPattern = 5;
+constexpr int kPatternPeriod[2] = {864, 2592};
 
 // MSK144 sync word (msk_context.cuh:149); kSync8Pm = 2*s8-1.
 constexpr int kSync8[8] = {0, 1, 1, 1, 0, 0, 1, 0};

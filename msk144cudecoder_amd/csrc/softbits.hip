@@ -212,6 +212,10 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     const size_t item0 = static_cast<size_t>(ch) * a.st.K + static_cast<size_t>(b) * ncand;
     uint32_t pos_of_lane = 0u;
     if(lane < D) pos_of_lane = a.st.pos[item0 + wave + kSbWaves * lane];
+    // Lanes 8..15 / 16..23: the eight scan positions of pattern 5 (mask 111111) / pattern 6 (mask 100100) of this tile, for the
+    // duplicate test of the candidate loop (kGateEarly only).
+    if(kGateEarly && lane >= kSlotsPerPattern && lane < 3 * kSlotsPerPattern && kFirstPeriodicPattern + (lane >> 3) - 1 < D)
+        pos_of_lane = a.st.pos[item0 + (kFirstPeriodicPattern + (lane >> 3) - 1) * kSlotsPerPattern + (lane & 7)];
 
     // ---- mix (softbits_kernel.cuh:27-52) ----
     const float f0 = -1.0f * a.st.freq[b];
@@ -304,6 +308,30 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const size_t item = item0 + c;
         uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), i));
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
+        // Masks 111111 and 100100 fold the same frames at pos and at pos + 864 (+ 2592): the scan's eight slots of such a pattern
+        // are mostly the copies of two or three peaks, one per period (exact ties in exact arithmetic: 73 % of the slots of pattern 5
+        // on the bench workload).  The reference demodulates and decodes every copy (softbits_kernel.cuh:56-83 folds them in another
+        // order: the same sums up to float association).  Here, when no LLR row outlives its block, a slot whose position is
+        // congruent to a LOWER slot's hands its work to that slot: it stores -1 - slot as its nbadsync, the index stage leaves
+        // it out, and the collect stage gives it the nbadsync and the decode of the slot it names (index.hip).  With the store
+        // retained every slot is computed on its own, as in the reference.
+        if(kGateEarly && i >= kFirstPeriodicPattern && i < kFirstPeriodicPattern + 2)
+        {
+            const uint32_t period = i == kFirstPeriodicPattern ? kFrameSamples : 3 * kFrameSamples;
+            const uint32_t mine = pos % period;
+            int first = -1;
+            for(int sl = wave - 1; sl >= 0; sl--)
+            {
+                uint32_t q = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), (i - kFirstPeriodicPattern + 1) * kSlotsPerPattern + sl));
+                if(q >= static_cast<uint32_t>(kWindowSamples)) q -= kWindowSamples;
+                if(q % period == mine) first = sl;
+            }
+            if(first >= 0)
+            {
+                if(lane == 0) a.st.nbadsync[item] = -1 - first;
+                continue;
+            }
+        }
 #ifdef MSK144_PHASE_STAMPS
         const uint64_t st_t0 = (stamp_row_ && tid < 64) ? stamp_now() : 0;
 #endif
