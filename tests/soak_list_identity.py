@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""One-off soak: the production result list (64-channel blocks, gated softbits, periodic copies handed to the lower slot of their
+group) against the retain-everything list (every candidate demodulated and decoded on its own, as the reference does) on many
+1024-channel bench windows - byte for byte.  A handed-over copy reports its lower slot's nbadsync / iterations / hard errors /
+payload; computed on its own (other float association of the same frame sums) those could differ only in a marginal case, which
+would show here as a differing record.
+
+    python tests/soak_list_identity.py [--ranks 6]   ->  one JSON line
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=6, help="input sets (bench.make_inputs(rank, 1024)), four windows each")
+    a = ap.parse_args()
+    import bench
+    from msk144cudecoder_amd import hipdecoder as hip
+    deep = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
+    tot = dict(lists=0, records=0, copies_among_records=0, differing_lists=0, differing_records=0)
+    with hip.HipDecoder(channels=1024, max_results=1 << 20, **deep) as prod, hip.HipDecoder(channels=1024, max_results=1 << 20, llr_block_channels=1024, **deep) as full:
+        for rank in range(a.ranks):
+            wins, _ = bench.make_inputs(rank, 1024)
+            bench._INPUTS.clear()
+            for t in range(wins.shape[0]):
+                prod.submit_audio(wins[t])
+                prod.decode()
+                p = prod.results().copy()
+                full.submit_audio(wins[t])
+                full.decode()
+                f = full.results().copy()
+                tot["lists"] += 1
+                tot["records"] += len(f)
+                # a record is a copy when a lower slot of its (channel, group) is congruent modulo 864 (pattern 5 at depth 6)
+                five = f[f["pattern_idx"] == 5]
+                key = five["channel"].astype(np.int64) * (1 << 20) + (five["item"] >> 3)
+                res = (five["pos"].astype(np.int64) % 5184) % 864
+                seen = {}
+                for k, r, it in zip(key, res, five["item"]):
+                    if (int(k), int(r)) in seen and seen[(int(k), int(r))] < it:
+                        tot["copies_among_records"] += 1
+                    seen.setdefault((int(k), int(r)), int(it))
+                if p.tobytes() != f.tobytes():
+                    tot["differing_lists"] += 1
+                    n = min(len(p), len(f))
+                    tot["differing_records"] += int(np.count_nonzero(p[:n] != f[:n])) + abs(len(p) - len(f))
+            print(f"rank {rank}: {tot}", file=sys.stderr, flush=True)
+    print(json.dumps(tot), flush=True)
+    return 0 if tot["differing_lists"] == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -222,6 +222,59 @@ def test_blocked_staging_equals_retained(hip):
     assert len(want) > 100
 
 
+@pytest.mark.parametrize("depth,width", [(6, 500.0), (8, 120.0)])
+def test_periodic_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
+    """Masks 111111 and 100100 fold the same frames at pos and pos + 864 (+ 2592), so the scan's eight slots of such a pattern are
+    mostly copies of two or three peaks (exact ties in exact arithmetic).  The reference demodulates and decodes each copy
+    (softbits_kernel.cuh:56-83, ldpc_kernel.cuh:100-249).  In blocked staging a slot whose position is congruent to a LOWER slot's of its
+    group is not computed: the index list leaves it out and the collect stage reports it with the nbadsync and the decode of that
+    slot.  Checked here on two channels (one with a strong ping, so that accepted copies exist): (1) the index list of the blocked
+    handle is exactly the retained handle's list minus the slots that have a congruent lower slot; (2) only patterns 5 and 6 lose
+    slots, most of pattern 5's; (3) the result lists of the two handles are byte-identical - the copies are reported, with their own
+    position and xb."""
+    cfg = dict(center=1500.0, width=width, step=1.0, depth=depth, nbadsync_threshold=3)
+    rng = np.random.default_rng(808)
+    msg = synth.random_message(rng)
+    wins = np.stack([synth.synth_audio(5184, [synth.Ping(msg, 200, 6, 1500.0 + 33.3, 3.0, 1.1)], 1000.0, rng),
+                     np.rint(rng.normal(0.0, 1000.0, 5184)).astype(np.int16)])
+    with hip.HipDecoder(channels=2, llr_block_channels=2, max_results=1 << 18, **cfg) as d:
+        d.submit_audio(wins)
+        d.decode()
+        full = d.results().copy()
+        items = [d.dump_candidates(c) for c in range(2)]
+        idx_full = [d.dump_indexes(c) for c in range(2)]
+    with hip.HipDecoder(channels=2, llr_block_channels=1, max_results=1 << 18, **cfg) as d:
+        d.submit_audio(wins)
+        d.decode()
+        blocked = d.results().copy()
+        idx_blocked = [d.dump_indexes(c) for c in range(2)]
+    assert blocked.tobytes() == full.tobytes() and len(full) > 20                                    # (3)
+    period = {5: 864, 6: 2592}
+    handed = kept = 0
+    accepted_copies = 0
+    for c in range(2):
+        it = items[c]
+        pos = it["pos"].astype(np.int64) % 5184
+        drop = np.zeros(len(it), dtype=bool)
+        for g0 in range(0, len(it), 8):
+            p = int(it["pattern_idx"][g0])
+            if p not in period:
+                continue
+            r = pos[g0:g0 + 8] % period[p]
+            for sl in range(1, 8):
+                drop[g0 + sl] = bool((r[:sl] == r[sl]).any())
+        want = np.array([k for k in idx_full[c] if not drop[k]], dtype=np.int32)
+        assert np.array_equal(idx_blocked[c], want), c                                                # (1)
+        handed += int(drop[idx_full[c]].sum())
+        kept += len(want)
+        five = it["pattern_idx"] == 5
+        assert drop[five].mean() > 0.5 and not drop[~np.isin(it["pattern_idx"], list(period))].any()  # (2)
+        accepted_copies += int((drop & (it["is_message_present"] == 1)).sum())
+    assert accepted_copies >= 1            # the list identity above covered records that were never decoded themselves
+    parity_report(f"periodic_copies_depth{depth}", dict(gated_slots_handed_over=handed, gated_slots_decoded=kept, accepted_copies_in_the_result_list=accepted_copies,
+                                                        result_lists_identical=True))
+
+
 def test_maximum_grid_single_channel(orc, hip, parity_report):
     """Largest search grid the option surface allows in practice: width 500 at a quarter-Hz step, all 8 patterns (F = 2001,
     128 064 candidates per window, threshold 4) - every stage against the oracle on one window with two pings."""
