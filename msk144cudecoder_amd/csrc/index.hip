@@ -43,9 +43,9 @@ __device__ __forceinline__ int ordered_slot(bool flag, int& base, int* s_wave_co
 }
 
 // index_kernel.cuh:30-50: a candidate goes to the LDPC when its sync words disagree in at most `threshold` bits.  A negative
-// value is not a count: softbits_kernel<true> stores -1 - s for a candidate of a periodic pattern (masks 111111, 100100) whose
-// folded frames are those of slot s < its own of the same (frequency, pattern) group - that slot is decoded, this one takes its
-// result in the collect stage (source_item below).
+// value is not a count: softbits_kernel<true> stores -1 - s for a candidate whose folded frames are those of slot s < its own
+// of the same (frequency, pattern) group (positions congruent modulo the ring, or modulo the period of masks 111111 / 100100) -
+// that slot is decoded, this one takes its result in the collect stage (source_item below).
 __device__ __forceinline__ bool passes_gate(int32_t nbad, int32_t threshold)
 {
     return nbad >= 0 && nbad <= threshold;

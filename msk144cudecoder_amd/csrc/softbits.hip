@@ -205,18 +205,14 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     MSK144_STAMP(0);
     MSK144_STAMP(11);  // two stamps back to back: the stamp's own cost
 
-    // Candidates of this wave: c = wave + 8 i, i < D.  Their scan positions are fetched once, lane i holding candidate i's
+    static_assert(kSbWaves == kSlotsPerPattern, "wave w owns slot w of every pattern: candidate c = w + 8 i is (pattern i, slot w)");
+    // Candidates of this wave: c = wave + 8 i, i < D.  The scan positions of all the tile's candidates are fetched once, one per lane
     // (the latency hides under the mix phase), and handed out by readlane: the position is a scalar in the candidate loop.
     const int D = a.st.D;
     const int ncand = D * kSlotsPerPattern;
     const size_t item0 = static_cast<size_t>(ch) * a.st.K + static_cast<size_t>(b) * ncand;
-    uint32_t pos_of_lane = 0u;
-    if(lane < D) pos_of_lane = a.st.pos[item0 + wave + kSbWaves * lane];
-    // Lanes 8..15 / 16..23: the eight scan positions of pattern 5 (mask 111111) / pattern 6 (mask 100100) of this tile, for the
-    // duplicate test of the candidate loop (kGateEarly only).
-    if(kGateEarly && lane >= kSlotsPerPattern && lane < 3 * kSlotsPerPattern && kFirstPeriodicPattern + (lane >> 3) - 1 < D)
-        pos_of_lane = a.st.pos[item0 + (kFirstPeriodicPattern + (lane >> 3) - 1) * kSlotsPerPattern + (lane & 7)];
-
+    uint32_t pos_of_lane = 0u;  // lane l: scan position of the tile's candidate l (pattern l / 8, slot l % 8)
+    if(lane < ncand) pos_of_lane = a.st.pos[item0 + lane];
     // ---- mix (softbits_kernel.cuh:27-52) ----
     const float f0 = -1.0f * a.st.freq[b];
     const float2* __restrict__ cdat = a.st.analytic + static_cast<size_t>(ch) * kWindowSamples;
@@ -248,6 +244,27 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
 #ifdef MSK144_PHASE_STAMPS
     uint64_t st_part1 = 0, st_part2 = 0, st_n2 = 0;  // wave 0: cycles in part one / part two of its candidates, part-two runs
 #endif
+
+    // Slots that fold the same frames.  The scan walks 5376 positions of a 5184-sample ring, so positions p and p + 5184 are one
+    // place (2.9 % of the slots of a noise window hold such a pair); masks 111111 and 100100 moreover sum the same frames at pos
+    // and pos + 864 (+ 2592), so the eight slots of those patterns are mostly the copies of two or three peaks, one per period
+    // (exact ties in exact arithmetic: 73 % of the slots of pattern 5 on the bench workload).  The reference demodulates and decodes
+    // every copy (softbits_kernel.cuh:56-83 folds the frames of a periodic copy in another order: the same sums up to float
+    // association; a wrapped copy is the same computation).  Here, when no LLR row outlives its block, a slot whose position is
+    // congruent to a LOWER slot's of its group hands its work to that slot: it stores -1 - slot as its nbadsync, the index stage
+    // leaves it out and the collect stage gives it the nbadsync and the decode of the slot it names (index.hip).  With the store
+    // retained every slot is computed on its own, as in the reference.
+    // Bit 8 i + s of same_frames: slot s of pattern i is congruent to THIS wave's slot of pattern i.
+    uint64_t same_frames = 0;
+    if(kGateEarly)
+    {
+        uint32_t r = pos_of_lane >= static_cast<uint32_t>(kWindowSamples) ? pos_of_lane - kWindowSamples : pos_of_lane;
+        const int pattern_of_lane = lane >> 3;
+        if(pattern_of_lane == kFirstPeriodicPattern) r %= static_cast<uint32_t>(kPatternPeriod[0]);
+        if(pattern_of_lane == kFirstPeriodicPattern + 1) r %= static_cast<uint32_t>(kPatternPeriod[1]);
+        const uint32_t mine = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(4 * ((lane & ~(kSlotsPerPattern - 1)) + wave), static_cast<int>(r)));
+        same_frames = __ballot(lane < ncand && r == mine);
+    }
 
     // Phase estimate = sum over the two sync words of folded sample x conj(template) (softbits_kernel.cuh:88-137).  The first
     // sync word covers samples 0..41 = groups 0..6 (lanes 0..6 of slot 0), the second samples 336..377 = groups 56..62.
@@ -306,29 +323,15 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const int c = wave + kSbWaves * i;
         const int p = c / kSlotsPerPattern;
         const size_t item = item0 + c;
-        uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), i));
+        uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), c));
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
-        // Masks 111111 and 100100 fold the same frames at pos and at pos + 864 (+ 2592): the scan's eight slots of such a pattern
-        // are mostly the copies of two or three peaks, one per period (exact ties in exact arithmetic: 73 % of the slots of pattern 5
-        // on the bench workload).  The reference demodulates and decodes every copy (softbits_kernel.cuh:56-83 folds them in another
-        // order: the same sums up to float association).  Here, when no LLR row outlives its block, a slot whose position is
-        // congruent to a LOWER slot's hands its work to that slot: it stores -1 - slot as its nbadsync, the index stage leaves
-        // it out, and the collect stage gives it the nbadsync and the decode of the slot it names (index.hip).  With the store
-        // retained every slot is computed on its own, as in the reference.
-        if(kGateEarly && i >= kFirstPeriodicPattern && i < kFirstPeriodicPattern + 2)
+        if(kGateEarly)
         {
-            const uint32_t period = i == kFirstPeriodicPattern ? kFrameSamples : 3 * kFrameSamples;
-            const uint32_t mine = pos % period;
-            int first = -1;
-            for(int sl = wave - 1; sl >= 0; sl--)
+            // a lower slot of this (frequency, pattern) group folds the same frames: it does the work, this slot names it
+            const uint32_t lower = static_cast<uint32_t>(same_frames >> (kSlotsPerPattern * i)) & ((1u << wave) - 1u);
+            if(lower != 0u)
             {
-                uint32_t q = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), (i - kFirstPeriodicPattern + 1) * kSlotsPerPattern + sl));
-                if(q >= static_cast<uint32_t>(kWindowSamples)) q -= kWindowSamples;
-                if(q % period == mine) first = sl;
-            }
-            if(first >= 0)
-            {
-                if(lane == 0) a.st.nbadsync[item] = -1 - first;
+                if(lane == 0) a.st.nbadsync[item] = -1 - __builtin_ctz(lower);
                 continue;
             }
         }

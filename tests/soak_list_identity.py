@@ -39,12 +39,12 @@ def main():
                 f = full.results().copy()
                 tot["lists"] += 1
                 tot["records"] += len(f)
-                # a record is a copy when a lower slot of its (channel, group) is congruent modulo 864 (pattern 5 at depth 6)
-                five = f[f["pattern_idx"] == 5]
-                key = five["channel"].astype(np.int64) * (1 << 20) + (five["item"] >> 3)
-                res = (five["pos"].astype(np.int64) % 5184) % 864
+                # a record is (at least) a copy when a lower ACCEPTED slot of its (channel, group) is congruent modulo the ring (5184) or,
+                # for pattern 5 (mask 111111), modulo 864
+                key = f["channel"].astype(np.int64) * (1 << 20) + (f["item"] >> 3)
+                res = np.where(f["pattern_idx"] == 5, (f["pos"].astype(np.int64) % 5184) % 864, f["pos"].astype(np.int64) % 5184)
                 seen = {}
-                for k, r, it in zip(key, res, five["item"]):
+                for k, r, it in zip(key, res, f["item"]):
                     if (int(k), int(r)) in seen and seen[(int(k), int(r))] < it:
                         tot["copies_among_records"] += 1
                     seen.setdefault((int(k), int(r)), int(it))

@@ -223,15 +223,16 @@ def test_blocked_staging_equals_retained(hip):
 
 
 @pytest.mark.parametrize("depth,width", [(6, 500.0), (8, 120.0)])
-def test_periodic_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
-    """Masks 111111 and 100100 fold the same frames at pos and pos + 864 (+ 2592), so the scan's eight slots of such a pattern are
-    mostly copies of two or three peaks (exact ties in exact arithmetic).  The reference demodulates and decodes each copy
-    (softbits_kernel.cuh:56-83, ldpc_kernel.cuh:100-249).  In blocked staging a slot whose position is congruent to a LOWER slot's of its
-    group is not computed: the index list leaves it out and the collect stage reports it with the nbadsync and the decode of that
-    slot.  Checked here on two channels (one with a strong ping, so that accepted copies exist): (1) the index list of the blocked
-    handle is exactly the retained handle's list minus the slots that have a congruent lower slot; (2) only patterns 5 and 6 lose
-    slots, most of pattern 5's; (3) the result lists of the two handles are byte-identical - the copies are reported, with their own
-    position and xb."""
+def test_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
+    """Slots of one (frequency, pattern) group that fold the SAME frames: the scan walks 5376 positions of a 5184-sample ring, so pos
+    and pos + 5184 are one place, and masks 111111 and 100100 sum the same frames at pos and pos + 864 (+ 2592), so the eight slots of
+    those patterns are mostly copies of two or three peaks (exact ties in exact arithmetic).  The reference demodulates and decodes
+    each copy (softbits_kernel.cuh:56-83, ldpc_kernel.cuh:100-249).  In blocked staging a slot whose position is congruent to a LOWER
+    slot's of its group is not computed: the index list leaves it out and the collect stage reports it with the nbadsync and the
+    decode of that slot.  Checked here on two channels (one with a strong ping, so that accepted copies exist): (1) the index list of
+    the blocked handle is exactly the retained handle's list minus the slots that have a congruent lower slot; (2) most slots of
+    pattern 5 are such copies, a few per cent elsewhere (ring wrap only); (3) the result lists of the two handles are byte-identical -
+    the copies are reported, with their own position and xb."""
     cfg = dict(center=1500.0, width=width, step=1.0, depth=depth, nbadsync_threshold=3)
     rng = np.random.default_rng(808)
     msg = synth.random_message(rng)
@@ -257,10 +258,7 @@ def test_periodic_copies_are_handed_to_the_lower_slot(hip, parity_report, depth,
         pos = it["pos"].astype(np.int64) % 5184
         drop = np.zeros(len(it), dtype=bool)
         for g0 in range(0, len(it), 8):
-            p = int(it["pattern_idx"][g0])
-            if p not in period:
-                continue
-            r = pos[g0:g0 + 8] % period[p]
+            r = pos[g0:g0 + 8] % period.get(int(it["pattern_idx"][g0]), 5184)
             for sl in range(1, 8):
                 drop[g0 + sl] = bool((r[:sl] == r[sl]).any())
         want = np.array([k for k in idx_full[c] if not drop[k]], dtype=np.int32)
@@ -268,11 +266,12 @@ def test_periodic_copies_are_handed_to_the_lower_slot(hip, parity_report, depth,
         handed += int(drop[idx_full[c]].sum())
         kept += len(want)
         five = it["pattern_idx"] == 5
-        assert drop[five].mean() > 0.5 and not drop[~np.isin(it["pattern_idx"], list(period))].any()  # (2)
+        wrap_only = ~np.isin(it["pattern_idx"], list(period))
+        assert drop[five].mean() > 0.5 and 0.0 < drop[wrap_only].mean() < 0.08                        # (2)
         accepted_copies += int((drop & (it["is_message_present"] == 1)).sum())
     assert accepted_copies >= 1            # the list identity above covered records that were never decoded themselves
-    parity_report(f"periodic_copies_depth{depth}", dict(gated_slots_handed_over=handed, gated_slots_decoded=kept, accepted_copies_in_the_result_list=accepted_copies,
-                                                        result_lists_identical=True))
+    parity_report(f"copies_handed_over_depth{depth}", dict(gated_slots_handed_over=handed, gated_slots_decoded=kept, accepted_copies_in_the_result_list=accepted_copies,
+                                                           result_lists_identical=True))
 
 
 def test_maximum_grid_single_channel(orc, hip, parity_report):
