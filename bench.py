@@ -643,11 +643,11 @@ def run_worker(args) -> int:
                        "softbits_gate_early": bool(llr_block < channels), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
                        "real_time_channels": value / be.K / (12000.0 / 2592.0),
                        "real_time_channels_note": "hot-clock GPU-only arithmetic (windows/s / 4.63 at the back-to-back clock of ~2.35 GHz).  The stream decoder program itself, "
-                                                  "measured over 60 s of signal per stream (tools/host_scale.py, profiles/r05_host_scale_*_60s*.json): 4096 real-time streams with every "
-                                                  "stream's hop falling due together - 0 late of 1.14 M hops, worst hop latency 193 ms of the 210 ms limit (the aligned worst case, 17 ms "
-                                                  "margin); with every stream on its own hop phase 4608 / 4864 / 5120 streams - 0 late, worst 54-66 ms; 5376 such streams overload the GPU "
-                                                  "(30-68 % late: 97 % of this line's figure leaves no slack for queueing).  A GPU that idles between hops starts each batch at 1.8-2.0 GHz "
-                                                  "(profiles/r04_idle_gap.json), so a lightly loaded program runs its kernels ~8 % slower than this line"},
+                                                  "measured over 60 s of signal per stream (tools/host_scale.py, profiles/r05_host_scale_*_60s_final.json): with every stream's hop "
+                                                  "falling due together 4096 real-time streams - 0 late of 1.14 M hops, worst hop latency 171 ms of the 210 ms limit - and 4608 at the "
+                                                  "edge (0 late, 193 ms); with every stream on its own hop phase 5376 / 5888 streams - 0 late, worst 52 / 66 ms.  A GPU that idles "
+                                                  "between hops starts each batch at 1.8-2.0 GHz (profiles/r04_idle_gap.json), so a lightly loaded program runs its kernels ~8 % slower "
+                                                  "than this line"},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_launch, "avg_launch_ms": dom_ms, "launches_per_step": launches,
