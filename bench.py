@@ -640,7 +640,8 @@ def run_worker(args) -> int:
                        "channels_per_gpu": channels, "candidates_per_step_per_gpu": cand_per_step, "parallelism": f"channel-shard x{world}",
                        "analytic_method": 2, "llr_block_channels": getattr(be, "llr_block", None),
                        "llr_store": f"blocked/{llr_block}" if llr_block < channels else "retained",
-                       "softbits_gate_early": bool(llr_block < channels), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
+                       "softbits_gate_early": bool(llr_block < channels),
+                       "copies_computed_once": bool(llr_block < channels), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
                        "real_time_channels": value / be.K / (12000.0 / 2592.0),
                        "real_time_channels_note": "hot-clock GPU-only arithmetic (windows/s / 4.63 at the back-to-back clock of ~2.35 GHz).  The stream decoder program itself, "
                                                   "measured over 60 s of signal per stream (tools/host_scale.py, profiles/r05_host_scale_*_60s_final.json): with every stream's hop "
@@ -653,7 +654,10 @@ def run_worker(args) -> int:
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_launch, "avg_launch_ms": dom_ms, "launches_per_step": launches,
                          "candidates_per_launch": cand_per_launch,
                          "mode": ("blocked staging: LLR rows are written only for candidates that pass the nbadsync gate and live for one "
-                                  f"{llr_block}-channel block; a gated-out candidate stops after its sync check (softbits_kernel<true>)")
+                                  f"{llr_block}-channel block; a gated-out candidate stops after its sync check (softbits_kernel<true>); a candidate that folds the same "
+                                  "frames as a lower slot of its (frequency, pattern) group - ring-wrap twins, the periodic copies of masks 111111 / 100100: 14 % of the slots "
+                                  "of a noise window - is neither demodulated nor decoded again and reports that slot's result (DESIGN.md 3; every slot is reported, the "
+                                  "list is byte-identical to computing each one)")
                                  if llr_block < channels else "retained: every candidate demodulated in full, every LLR row kept (parity-dump mode)",
                          "note": "the contract's HBM figure; the path is VALU-issue/LDS-pipe bound (SURVEY.md 8d) - the binding roofline is roofline_valu"},
             "roofline_valu": roofline_valu(valu, lds, dom),
