@@ -28,7 +28,7 @@ def test_deep_window_against_oracle(orc, hip, parity_report):
     rep = parity.compare_scan(o, cd, items_o, items_g)
     assert rep["near_ties"] + rep["periodic_fallbacks"] <= parity.near_tie_limit(24048) == 3, rep   # measured-rate limit (parity.py); observed 0
     sb = parity.compare_softbits(o, cd, items_o, items_g)
-    assert sb["nbadsync_marginal"] <= parity.nbadsync_marginal_limit(24048) == 1, sb
+    assert sb["nbadsync_marginal_classes"] <= parity.nbadsync_marginal_limit(24048) == 1, sb
     assert sb["llr_max_rel_diff"] <= parity.TOL_LLR_REGRESSION
     assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= 3)[0])
     same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
