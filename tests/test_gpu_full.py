@@ -35,7 +35,7 @@ def test_deep_window_against_oracle(orc, hip, parity_report):
     # accept / iterations / hard errors / payload identical wherever the candidate itself is identical; any difference
     # must be a VERIFIED marginal case (oracle decision unstable under 1e-6..1e-4 LLR perturbations)
     ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
-    assert ld["marginal_flips"] <= parity.bp_marginal_limit(24048) == 2, ld
+    assert ld["marginal_classes"] <= parity.bp_marginal_limit(24048) == 2, ld
     assert ld["both_accepted"] > 10
     parity_report("deep_window_F501_D6", dict(scan=rep, softbits=sb, ldpc=ld))
     assert bytes(msg) in parity.decoded_messages(items_g)
@@ -122,7 +122,7 @@ def test_fine_step_depth8_all_gated(orc, hip, parity_report):
     parity.compare_softbits(o, cd, items_o, items_g)
     same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
     ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
-    assert ld["marginal_flips"] <= parity.bp_marginal_limit(25664), ld
+    assert ld["marginal_classes"] <= parity.bp_marginal_limit(25664), ld
     parity_report("fine_step_depth8_all_gated", dict(scan=rep, ldpc=ld))
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
     assert bytes(msg) in parity.decoded_messages(items_g)
@@ -298,7 +298,7 @@ def test_maximum_grid_single_channel(orc, hip, parity_report):
     assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= 4)[0])
     same = (items_o["pos"] == items_g["pos"]) & (items_o["nbadsync"] == items_g["nbadsync"])
     ld = parity.compare_ldpc_items(orc, items_o, items_g, same)
-    assert ld["marginal_flips"] <= parity.bp_marginal_limit(128064), ld
+    assert ld["marginal_classes"] <= parity.bp_marginal_limit(128064), ld
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
     assert {bytes(m1), bytes(m2)} <= parity.decoded_messages(items_g)
     assert np.array_equal(res["item"], np.nonzero(items_g["is_message_present"])[0])

@@ -61,7 +61,7 @@ def test_random_configuration(orc, hip, parity_report, seed):
     sb = parity.compare_softbits(o, cd_g, items_o, items_g)
     assert np.array_equal(idx_g, np.nonzero(items_g["nbadsync"] <= cfg["nbadsync_threshold"])[0])
     ld = parity.compare_ldpc_against_oracle_on_gpu_llrs(orc, items_g, cfg["nbadsync_threshold"])
-    assert ld["marginal_flips"] <= ld["marginal_limit"] <= 1, ld          # each one verified unstable by parity.verify_marginal_bp; the limit follows the measured rate
+    assert ld["marginal_classes"] <= ld["marginal_limit"] <= 1, ld          # each one verified unstable by parity.verify_marginal_bp; the limit follows the measured rate
     parity_report(f"fuzz_seed{seed}", dict(config=dict(cfg, read_mode=read_mode, analytic_method=method), scan=rep, softbits=sb, ldpc=ld))
     assert parity.decoded_messages(items_g) == parity.decoded_messages(items_o)
 

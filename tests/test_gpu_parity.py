@@ -124,7 +124,7 @@ def test_stages_against_oracle(orc, hip, parity_report, ci, seed):
         assert np.array_equal(idx_g, idx_o)
 
     ld = parity.compare_ldpc_against_oracle_on_gpu_llrs(orc, items_g, cfg["nbadsync_threshold"])
-    assert ld["marginal_flips"] <= ld["marginal_limit"] <= 1, ld          # each one verified unstable by parity.verify_marginal_bp
+    assert ld["marginal_classes"] <= ld["marginal_limit"] <= 1, ld          # each one verified unstable by parity.verify_marginal_bp
     parity_report(f"stages_cfg{ci}_seed{seed}", dict(scan=rep, softbits=sb, ldpc=ld))
 
     # decoded payloads: same set of messages as the oracle, and it is the transmitted one
