@@ -515,3 +515,31 @@ def test_cli_two_different_devices_equal_two_single_device_runs(hip, tmp_path):
         want.update(by_channel(o1, 3 * half))
     assert by_channel(out) == want and len(want) >= 4
     assert "device 0 decodes streams 0..2" in err and "device 1 decodes streams 3..5" in err
+
+
+@pytest.mark.parametrize("name,args,cfg,read_mode,method", [
+    ("fft_front_end", ["--analytic-method=1", "--search-width=24", "--search-step=1", "--scan-depth=5", "--nbadsync-threshold=2"],
+     dict(center=1500.0, width=24.0, step=1.0, depth=5, nbadsync_threshold=2), 1, 1),
+    ("depth8_fractional_step_offset_centre", ["--center-frequency=1512.5", "--search-width=9", "--search-step=0.75", "--scan-depth=8", "--nbadsync-threshold=4"],
+     dict(center=1512.5, width=9.0, step=0.75, depth=8, nbadsync_threshold=4), 1, 2),
+    ("iq_depth_clamped", ["--read-mode=2", "--center-frequency=-3", "--search-width=14", "--search-step=1", "--scan-depth=11", "--nbadsync-threshold=3"],
+     dict(center=-3.0, width=14.0, step=1.0, depth=8, nbadsync_threshold=3), 2, 2),          # scan depth is clamped to 8 (msk_context.cuh:29-33)
+])
+def test_cli_option_surface_against_oracle(orc, name, args, cfg, read_mode, method):
+    """Corners of the reference's option surface (main.cu:136-190) through the program, line for line against the oracle-driven decoder in
+    both text modes: the FFT front end (--analytic-method=1, analytic_fft.cu), all eight averaging patterns with a fractional search
+    step around an offset centre frequency (msk_context.cuh:95-113), and IQ input with a scan depth beyond the clamp."""
+    from oracle import oracle_cli
+    rng = np.random.default_rng({"fft_front_end": 521, "depth8_fractional_step_offset_centre": 806, "iq_depth_clamped": 430}[name])
+    n = 5184 + 3 * 2592
+    f0 = cfg["center"] + 1.5
+    msgs = [pack77.pack_standard("CQ", "K1ABC", "FN42"), pack77.pack_standard("K1ABC", "W9XYZ", "R-05")]
+    pings = [synth.Ping(msgs[0], 700, 6, f0, 5.0, 0.3), synth.Ping(msgs[1], 5184 + 900, 4, f0 - 2.0, 5.0, 1.3)]
+    stream = synth.synth_audio(n, pings, 1000.0, rng) if read_mode == 1 else synth.synth_iq(n, pings, 20.0, rng)
+    for extra, quirk in (([], True), (["--strict-decode"], False)):
+        rc, out, err = _run(args + extra, stream.tobytes())
+        assert rc == 0, err
+        want = oracle_cli.decode_stream(stream, cfg, read_mode, method, quirk=quirk, threads=8)
+        assert _lines(out) == want, (name, quirk)
+        assert len(want) >= 2
+    assert f"Scan Depth: {cfg['depth']}" in err
