@@ -274,6 +274,30 @@ def test_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
                                                            result_lists_identical=True))
 
 
+def test_silent_and_saturated_channels_in_a_blocked_batch(hip):
+    """An all-zero window (1/0 normalisation: NaN samples, NaN correlations, arbitrary scan positions - possibly eight equal ones, i.e.
+    seven copies per group) and a full-scale square wave inside a batch that is decoded in blocks with copies handed over: the list equals
+    the retain-everything list byte for byte, the silent channel reports nothing and disturbs no one."""
+    cfg = dict(center=1500.0, width=60.0, step=1.0, depth=6, nbadsync_threshold=3)
+    rng = np.random.default_rng(31)
+    n_ch = 70
+    wins = np.rint(rng.normal(0.0, 1000.0, size=(n_ch, 5184))).astype(np.int16)
+    msg = synth.random_message(rng)
+    for c in (0, 33, 69):
+        wins[c] = synth.synth_audio(5184, [synth.Ping(msg, 300 + c, 6, 1500.0 + 0.3 * c, 4.0, 0.1 * c)], 1000.0, rng)
+    wins[5] = 0
+    wins[66] = np.where(np.arange(5184) % 8 < 4, 32767, -32768).astype(np.int16)
+    lists = []
+    for blk in (n_ch, 64, 9):
+        with hip.HipDecoder(channels=n_ch, llr_block_channels=blk, max_results=1 << 18, **cfg) as d:
+            d.submit_audio(wins)
+            d.decode()
+            lists.append(d.results().copy())
+    assert lists[0].tobytes() == lists[1].tobytes() == lists[2].tobytes()
+    got = set(int(c) for c in lists[0]["channel"])
+    assert {0, 33, 69} <= got and 5 not in got
+
+
 def test_maximum_grid_single_channel(orc, hip, parity_report):
     """Largest search grid the option surface allows in practice: width 500 at a quarter-Hz step, all 8 patterns (F = 2001,
     128 064 candidates per window, threshold 4) - every stage against the oracle on one window with two pings."""
