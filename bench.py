@@ -304,6 +304,34 @@ def sustained_leg(be, step, fence, n_steps: int, first_index: int, depth: int = 
                     "one-wave probe beside the running steps (s_memtime / s_memrealtime x 100 MHz); `value` is NOT taken from this leg"}
 
 
+def every_slot_leg(be, n_steps: int, first_index: int):
+    """The same step on the same inputs with the copy hand-over switched OFF (msk144_set_copy_handover(h, 0)): every one of the
+    F*D*8 slots of every window is demodulated (up to the nbadsync gate) and, when gated, decoded on its own - what the reference's
+    softbits_kernel / ldpc_kernel do (softbits_kernel.cuh:56-83, ldpc_kernel.cuh:100-249) and what SURVEY.md 8(d) calls a slot "fully
+    evaluated".  Blocked staging and the early gate stay as in the timed region.  Reported beside `value`, never as `value`."""
+    dec = be.dec
+    dec.set_copy_handover(False)
+    try:
+        for i in range(2):
+            be.step(first_index + i)
+        be.fence()
+        dec.stage_times(reset=True)
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            be.step(first_index + 2 + i)
+        be.fence()
+        el = time.perf_counter() - t0
+        st = dec.stage_times(reset=True)
+        handed = dec.copy_count()
+        records = len(dec.results())
+    finally:
+        dec.set_copy_handover(True)
+    return {"value": be.cand_per_step * n_steps / el, "unit": "candidates/s", "steps": n_steps, "warmup": 2, "ms_per_step": el / n_steps * 1e3,
+            "stage_ms": {n: round(st[n][0], 4) for n in be.T_NAMES}, "slots_handed_over": handed, "records_last_step": records,
+            "note": "copy hand-over off: every slot demodulated / decoded on its own as in the reference; same inputs, same handle, blocked staging and early "
+                    "nbadsync gate unchanged; run after the timed region"}
+
+
 def pcie_leg(be, n_steps: int):
     """The same step with the windows coming from pinned HOST memory (the reference's hop includes its H2D copy, main.cu:325): each
     step is msk144_submit_slot (asynchronous H2D of the slot's 1024 windows + front end), msk144_decode, msk144_fetch_async
@@ -560,6 +588,15 @@ def run_worker(args) -> int:
         st2 = be.stage_times()      # averages over the timed region AND the sustained leg (profiling stayed on)
         sustained["stage_ms_incl_timed_region"] = {n: round(st2[n][0], 4) for n in be.T_NAMES}
     last = be.results()         # of the last step run (the sustained leg's when there is one): what the last gather must have carried
+    # What `value` counts: every slot is REPORTED each step; with the hand-over on (the default of blocked staging) some are not computed
+    # again.  The share of the last step, and - same inputs, same box, right after the timed region - the rate with every slot computed.
+    handover = None
+    if Backend is HipBackend:
+        on = be.dec.copy_handover()
+        handed = be.dec.copy_count()
+        handover = {"enabled": on, "slots_handed_over_last_step": handed, "share_of_slots": handed / cand_per_step}
+        if on:
+            handover["value_every_slot_decoded"] = every_slot_leg(be, max(4, min(args.steps, 10)), args.warmup + args.steps)
     # Short extra legs, single-GPU runs of the product backend only (each on rank 0 would leave the other ranks waiting): after
     # everything the main line reports has been read, so they cannot disturb it.
     extra = {}
@@ -630,6 +667,18 @@ def run_worker(args) -> int:
                     static = "profiles/counters.json is stale for these kernel sources: traffic/valu_issue omitted"
             except Exception as e:  # noqa: BLE001
                 static = f"profiles/counters.json unreadable: {e}"
+        if llr_block >= channels:
+            mode = "retained: every candidate demodulated in full, every LLR row kept (parity-dump mode)"
+        else:
+            mode = ("blocked staging: LLR rows are written only for candidates that pass the nbadsync gate and live for one "
+                    f"{llr_block}-channel block; a gated-out candidate stops after its sync check (softbits_kernel<true, .>); a candidate that folds the same "
+                    "frames as a lower slot of its (frequency, pattern) group - ring-wrap twins, the periodic copies of masks 111111 / 100100 - ")
+            if handover and handover["enabled"]:
+                mode += (f"is neither demodulated nor decoded again and reports that slot's result: {100.0 * handover['share_of_slots']:.1f} % of the slots of this "
+                         "run's last step (DESIGN.md 3; every slot is reported, the list is byte-identical to computing each one; value_every_slot_decoded = "
+                         "the same step with the hand-over off)")
+            else:
+                mode += "is computed again, as in the reference (copy hand-over off or not reported by this backend)"
         out = {
             "metric": "candidate decodes/sec (scan+softbits+LDPC), width=500 step=1 depth=6",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -641,7 +690,13 @@ def run_worker(args) -> int:
                        "analytic_method": 2, "llr_block_channels": getattr(be, "llr_block", None),
                        "llr_store": f"blocked/{llr_block}" if llr_block < channels else "retained",
                        "softbits_gate_early": bool(llr_block < channels),
-                       "copies_computed_once": bool(llr_block < channels), "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
+                       "copies_computed_once": bool(handover["enabled"]) if handover else bool(llr_block < channels),
+                       "value_counts": (f"ResultItem slots REPORTED per second (every slot of every window, each step); {100.0 * handover['share_of_slots']:.1f} % of them "
+                                        "(measured on the last step of this run) fold the same frames as a lower slot of their group and were handed over - not "
+                                        "demodulated / decoded again, they report that slot's result; `value_every_slot_decoded` is the same step with every slot "
+                                        "computed on its own, as the reference does") if handover and handover["enabled"]
+                                       else "ResultItem slots fully evaluated per second (every slot demodulated up to the nbadsync gate and, when gated, decoded)",
+                       "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
                        "real_time_channels": value / be.K / (12000.0 / 2592.0),
                        "real_time_channels_note": "hot-clock GPU-only arithmetic (windows/s / 4.63 at the back-to-back clock of ~2.35 GHz).  The stream decoder program itself, "
                                                   "measured over 60 s of signal per stream (tools/host_scale.py, profiles/r05_host_scale_*_60s_final.json): with every stream's hop "
@@ -653,12 +708,7 @@ def run_worker(args) -> int:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": static,
                          "algorithmic_bytes_per_launch": B_ALG_PER_CANDIDATE * cand_per_launch, "avg_launch_ms": dom_ms, "launches_per_step": launches,
                          "candidates_per_launch": cand_per_launch,
-                         "mode": ("blocked staging: LLR rows are written only for candidates that pass the nbadsync gate and live for one "
-                                  f"{llr_block}-channel block; a gated-out candidate stops after its sync check (softbits_kernel<true>); a candidate that folds the same "
-                                  "frames as a lower slot of its (frequency, pattern) group - ring-wrap twins, the periodic copies of masks 111111 / 100100: 14 % of the slots "
-                                  "of a noise window - is neither demodulated nor decoded again and reports that slot's result (DESIGN.md 3; every slot is reported, the "
-                                  "list is byte-identical to computing each one)")
-                                 if llr_block < channels else "retained: every candidate demodulated in full, every LLR row kept (parity-dump mode)",
+                         "mode": mode,
                          "note": "the contract's HBM figure; the path is VALU-issue/LDS-pipe bound (SURVEY.md 8d) - the binding roofline is roofline_valu"},
             "roofline_valu": roofline_valu(valu, lds, dom),
             "valu_issue": valu,
@@ -671,6 +721,11 @@ def run_worker(args) -> int:
             out["gather"] = {"records_last_step": gathered_records, "capacity_per_rank": gather.cap, "bytes_per_rank": int(gather.send.numel()),
                              "peak_records_per_rank": [int(x) for x in gather.max_total.cpu().numpy()], "backend": Backend.dist_backend,
                              "ms_per_step": gather.mean_ms(), "ms_note": "copy into the send buffer + gather, timed on rank 0 around RecordGather.step"}
+        if handover is not None:
+            every = handover.pop("value_every_slot_decoded", None)
+            out["copy_handover"] = handover
+            if every is not None:
+                out["value_every_slot_decoded"] = every
         if sustained is not None:
             out["sustained"] = sustained
         out.update(extra)

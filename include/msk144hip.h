@@ -24,6 +24,10 @@
  *   msk144_destroy           ~MSK144SearchContext / deinit        msk_context.cuh:81-120
  *   msk144_device_count      cudaGetDeviceCount behind cudaSetDeviceFlags (the reference drives device 0 only; the multi-device
  *                            stream program asks how many it may split its streams over)   main.cu:115
+ *   msk144_set_llr_retention whether the 128 softbits of every candidate stay readable after the decode, as in the reference's
+ *                            ResultItem array (result_keeper.cuh:17-32, 105-115) - the stream program never reads them
+ *   msk144_set_copy_handover whether slots that fold the same frames as a lower slot of their group are computed again, as
+ *   msk144_copy_count        softbits_kernel / ldpc_kernel do for every slot (softbits_kernel.cuh:56-83, ldpc_kernel.cuh:100-249)
  *   msk144_clock_probe       gpu_timer.h's role for the one figure HIP events cannot give: the shader clock a running batch
  *                            actually gets (s_memtime / s_memrealtime), read beside it on a side stream
  *
@@ -190,6 +194,31 @@ int msk144_results_device(msk144_handle* h, const msk144_result** d_records, con
  * msk144_result.channel = base + local channel, so that the records of a rank that owns channels
  * [base, base+channels) carry global channel ids when they are gathered.  Default 0. */
 int msk144_set_channel_base(msk144_handle* h, int32_t base);
+
+/* Copies (no reference counterpart: the reference demodulates and decodes every one of its F*D*8 slots, softbits_kernel.cuh:56-83,
+ * ldpc_kernel.cuh:100-249).  Two slots of one (frequency, pattern) group whose scan positions are congruent modulo the 5184-sample
+ * ring - or, for masks 111111 / 100100, modulo their period 864 / 2592 - fold the SAME frames.  In blocked staging
+ * (llr_block_channels < channels: no LLR row outlives its block) such a slot is by default not computed again: it reports the
+ * nbadsync, iterations, hard errors and payload of the LOWEST congruent slot of its group, with its own position and xb.
+ *   msk144_set_copy_handover(h, 0)  every slot is demodulated and decoded on its own, as in the reference (still blocked staging,
+ *                                   still no demodulation beyond the sync check for candidates the nbadsync gate drops);
+ *   msk144_set_copy_handover(h, 1)  the default of a blocked handle; MSK144_ENOTRETAINED on a handle that retains every LLR row
+ *                                   (such a handle always computes every slot: its dumps show each slot's own row).
+ * Takes effect at the next decode.  msk144_copy_count: slots of the last decode that were handed over (0 when switched off). */
+int msk144_set_copy_handover(msk144_handle* h, int32_t enable);
+/* A handle whose one block covers all its channels (llr_block_channels = channels; the default up to 64 channels, e.g. the single
+ * stream of the reference's program) keeps every candidate's 128 softbits readable after the decode, as the reference's ResultItem
+ * array does (result_keeper.cuh:17-32): msk144_dump_candidates, partial stage runs and msk144_load_candidates work, and every slot is
+ * demodulated in full.  A caller that only reads the result list - the stream program - says so with
+ *   msk144_set_llr_retention(h, 0)  the handle behaves like a blocked one: a candidate the nbadsync gate drops stops after its sync
+ *                                   check, copies are handed over (above), dumps / partial stage runs / loaded candidates are refused
+ *                                   with MSK144_ENOTRETAINED - the kernels bench.py times at 1024 channels;
+ *   msk144_set_llr_retention(h, 1)  back to retaining; MSK144_ENOTRETAINED on a handle created with fewer channels per block than
+ *                                   channels.
+ * Takes effect at the next decode. */
+int msk144_set_llr_retention(msk144_handle* h, int32_t retain);
+int msk144_copy_handover(const msk144_handle* h, int32_t* enabled);
+int msk144_copy_count(msk144_handle* h, int64_t* slots);
 
 int msk144_segment_power(msk144_handle* h, float* out /*[channels][8]*/);
 

@@ -131,20 +131,38 @@ __global__ __launch_bounds__(kIdxThreads) void index_kernel(const DeviceStore st
 __global__ __launch_bounds__(kIdxThreads) void collect_count_kernel(const DeviceStore st)
 {
     __shared__ int s_wave_count[kIdxWaves];
+    __shared__ int s_wave_copies[kIdxWaves];
     const int ch = blockIdx.x;
     const size_t off = static_cast<size_t>(ch) * st.K;
     const int32_t* __restrict__ nbad = st.nbadsync + off;
-    int cnt = 0;
-    for(int k = threadIdx.x; k < st.K; k += kIdxThreads) cnt += st.dec_flag[off + source_item(nbad, k)] ? 1 : 0;
+    int cnt = 0, copies = 0;  // accepted decodes; slots that were handed to a lower slot (nbadsync < 0)
+    for(int k = threadIdx.x; k < st.K; k += kIdxThreads)
+    {
+        cnt += st.dec_flag[off + source_item(nbad, k)] ? 1 : 0;
+        copies += nbad[k] < 0 ? 1 : 0;
+    }
     // wave reduce
-    for(int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
-    if((threadIdx.x & 63) == 0) s_wave_count[threadIdx.x >> 6] = cnt;
+    for(int d = 32; d > 0; d >>= 1)
+    {
+        cnt += __shfl_down(cnt, d);
+        copies += __shfl_down(copies, d);
+    }
+    if((threadIdx.x & 63) == 0)
+    {
+        s_wave_count[threadIdx.x >> 6] = cnt;
+        s_wave_copies[threadIdx.x >> 6] = copies;
+    }
     __syncthreads();
     if(threadIdx.x == 0)
     {
-        int total = 0;
-        for(int w = 0; w < kIdxWaves; w++) total += s_wave_count[w];
+        int total = 0, total_copies = 0;
+        for(int w = 0; w < kIdxWaves; w++)
+        {
+            total += s_wave_count[w];
+            total_copies += s_wave_copies[w];
+        }
         st.dec_count[ch] = total;
+        st.copy_count[ch] = total_copies;
     }
 }
 

@@ -39,6 +39,7 @@ struct msk144_handle
     std::vector<void*> allocs;
 
     int llr_block = 1;  // channels per softbits->index->LDPC block
+    bool retained = true;  // every LLR row of a decode stays readable (one block covers all channels and msk144_set_llr_retention was not switched off)
     int active = 1;     // channels the current hop covers (msk144_submit_slot_n: the first n of the slot); <= st.channels
     bool have_window = false;
     bool decoded = false;
@@ -92,6 +93,19 @@ struct msk144_handle
     // msk144_clock_probe: its own stream, so that the probe wave runs beside the decode kernels
     hipStream_t probe_stream = nullptr;
     uint64_t* d_probe = nullptr;
+
+    // EXPERIMENT (msk144_set_graph_replay): the launches of one full decode captured once per launch shape and replayed
+    struct GraphKey
+    {
+        int active, slot_records, channel_base, handover, gate_early;
+        hipStream_t stream;
+        bool operator==(const GraphKey& o) const
+        {
+            return active == o.active && slot_records == o.slot_records && channel_base == o.channel_base && handover == o.handover && gate_early == o.gate_early && stream == o.stream;
+        }
+    };
+    bool graph_replay = false;
+    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
 
     std::string error;
 };
@@ -404,7 +418,9 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     st.nbadsync_threshold = params->nbadsync_threshold;
     st.ch0 = 0;
     st.nch = st.channels;
-    st.gate_early = h->llr_block < st.channels ? 1 : 0;
+    h->retained = h->llr_block >= st.channels;
+    st.gate_early = h->retained ? 0 : 1;
+    st.handover = st.gate_early;  // msk144_set_copy_handover
     h->active = st.channels;
     const long long total = static_cast<long long>(st.channels) * st.K;
     long long maxr = params->max_results > 0 ? params->max_results : (1 << 20);
@@ -445,6 +461,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     A(dev_alloc(h, &st.dec_nhard, ck));
     A(dev_alloc(h, &st.dec_msg, ck * 3));
     A(dev_alloc(h, &st.dec_count, st.channels));
+    A(dev_alloc(h, &st.copy_count, st.channels));
     A(dev_alloc(h, &st.result_count, 1));
     {
         msk144_result* r = nullptr;
@@ -472,6 +489,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     ok = ok && hipMemsetAsync(st.dec_flag, 0, ck, s0) == hipSuccess;
     ok = ok && hipMemsetAsync(st.n_idx, 0, sizeof(int32_t) * st.channels, s0) == hipSuccess;
     ok = ok && hipMemsetAsync(st.dec_count, 0, sizeof(int32_t) * st.channels, s0) == hipSuccess;
+    ok = ok && hipMemsetAsync(st.copy_count, 0, sizeof(int32_t) * st.channels, s0) == hipSuccess;
     ok = ok && hipMemsetAsync(st.result_count, 0, sizeof(int32_t), s0) == hipSuccess;
     ok = ok && hipMemsetAsync(st.pos, 0, ck * sizeof(uint32_t), s0) == hipSuccess;
     ok = ok && hipMemsetAsync(st.nbadsync, 0, ck * sizeof(int32_t), s0) == hipSuccess;
@@ -525,6 +543,7 @@ void msk144_destroy(msk144_handle* h)
         (void)hipEventDestroy(sp.e0);
         (void)hipEventDestroy(sp.e1);
     }
+    for(auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
     for(hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if(h->ev_open) (void)hipEventDestroy(h->ev_open);
     if(h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -616,14 +635,52 @@ int msk144_submit_analytic(msk144_handle* h, const float* windows)
     return MSK144_OK;
 }
 
+static int launch_stages(msk144_handle* h, uint32_t stages);
+
+int msk144_set_graph_replay(msk144_handle* h, int32_t enable)
+{
+    if(!h) return MSK144_EINVAL;
+    h->graph_replay = enable != 0;
+    return MSK144_OK;
+}
+
 int msk144_decode_stages(msk144_handle* h, uint32_t stages)
+{
+    if(h && h->graph_replay && stages == MSK144_STAGE_ALL && !h->profiling && h->have_window)
+    {
+        HIP_TRY(h, hipSetDevice(h->params.device));
+        const msk144_handle::GraphKey key{h->active, h->slots_ready ? h->cur_slot : -1, h->st.channel_base, h->st.handover, h->st.gate_early, h->stream};
+        hipGraphExec_t exec = nullptr;
+        for(auto& g : h->graphs)
+            if(g.first == key) exec = g.second;
+        if(!exec)
+        {
+            hipGraph_t graph = nullptr;
+            HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = launch_stages(h, stages);
+            const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+            if(rc != MSK144_OK) return rc;
+            if(e != hipSuccess) return fail(h, MSK144_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            HIP_TRY(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            h->graphs.emplace_back(key, exec);
+        }
+        h->call_id++;
+        HIP_TRY(h, hipGraphLaunch(exec, h->stream));
+        h->decoded = true;
+        return MSK144_OK;
+    }
+    return launch_stages(h, stages);
+}
+
+static int launch_stages(msk144_handle* h, uint32_t stages)
 {
     if(!h) return MSK144_EINVAL;
     if((stages & (MSK144_STAGE_SCAN | MSK144_STAGE_SOFTBITS)) && !h->have_window) return fail(h, MSK144_ESTATE, "decode before any window was submitted");
-    const bool blocked = h->llr_block < h->st.channels;
+    const bool blocked = !h->retained;
     const uint32_t mid = MSK144_STAGE_SOFTBITS | MSK144_STAGE_INDEX | MSK144_STAGE_LDPC;
     if(blocked && (stages & mid) != 0 && (stages & mid) != mid)
-        return fail(h, MSK144_ENOTRETAINED, "blocked staging runs softbits, index and LDPC together per channel block; a partial stage run needs llr_block_channels = channels");
+        return fail(h, MSK144_ENOTRETAINED, "LLR rows are not retained (blocked staging, or msk144_set_llr_retention(h, 0)): softbits, index and LDPC run together per channel block; a partial stage run needs llr_block_channels = channels");
     HIP_TRY(h, hipSetDevice(h->params.device));
     h->call_id++;
     if(h->profiling) harvest_finished(h);
@@ -727,6 +784,47 @@ int msk144_set_channel_base(msk144_handle* h, int32_t base)
     if(!h) return MSK144_EINVAL;
     if(base < 0) return fail(h, MSK144_EINVAL, "channel base must be >= 0");
     h->st.channel_base = base;  // kernel argument by value: takes effect at the next decode
+    return MSK144_OK;
+}
+
+int msk144_set_llr_retention(msk144_handle* h, int32_t retain)
+{
+    if(!h) return MSK144_EINVAL;
+    if(retain && h->llr_block < h->st.channels)
+        return fail(h, MSK144_ENOTRETAINED, "this handle decodes in blocks of fewer channels than it holds: an LLR row never outlives its block; create it with llr_block_channels = channels");
+    h->retained = retain != 0;
+    h->st.gate_early = h->retained ? 0 : 1;
+    h->st.handover = h->st.gate_early;
+    return MSK144_OK;
+}
+
+int msk144_set_copy_handover(msk144_handle* h, int32_t enable)
+{
+    if(!h) return MSK144_EINVAL;
+    if(enable && h->retained)
+        return fail(h, MSK144_ENOTRETAINED, "every LLR row of this handle is retained (llr_block_channels = channels): every slot is computed on its own; copies are handed over only when no row outlives its block (blocked staging, or msk144_set_llr_retention(h, 0))");
+    h->st.handover = enable ? 1 : 0;  // kernel argument by value: takes effect at the next decode
+    return MSK144_OK;
+}
+
+int msk144_copy_handover(const msk144_handle* h, int32_t* enabled)
+{
+    if(!h || !enabled) return MSK144_EINVAL;
+    *enabled = h->st.handover;
+    return MSK144_OK;
+}
+
+int msk144_copy_count(msk144_handle* h, int64_t* slots)
+{
+    if(!h || !slots) return fail(h, MSK144_EINVAL, "null argument");
+    if(!h->decoded) return fail(h, MSK144_ESTATE, "no decode has been run");
+    int rc = msk144_synchronize(h);
+    if(rc != MSK144_OK) return rc;
+    std::vector<int32_t> per_channel(static_cast<size_t>(h->active));
+    HIP_TRY(h, hipMemcpy(per_channel.data(), h->st.copy_count, sizeof(int32_t) * per_channel.size(), hipMemcpyDeviceToHost));
+    int64_t total = 0;
+    for(int32_t c : per_channel) total += c;
+    *slots = total;
     return MSK144_OK;
 }
 
@@ -876,7 +974,7 @@ int msk144_dump_analytic(msk144_handle* h, int32_t channel, float* out)
 int msk144_dump_candidates(msk144_handle* h, int32_t channel, msk144_candidate* out)
 {
     if(!h || !out || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
-    if(h->llr_block < h->st.channels) return fail(h, MSK144_ENOTRETAINED, "LLR rows are not retained in blocked staging; create the handle with llr_block_channels = channels for candidate dumps");
+    if(!h->retained) return fail(h, MSK144_ENOTRETAINED, "LLR rows are not retained (blocked staging, or msk144_set_llr_retention(h, 0)); create the handle with llr_block_channels = channels for candidate dumps");
     int rc = msk144_synchronize(h);
     if(rc != MSK144_OK) return rc;
     const DeviceStore& st = h->st;
@@ -933,7 +1031,7 @@ int msk144_dump_indexes(msk144_handle* h, int32_t channel, int32_t* out, int32_t
 int msk144_load_candidates(msk144_handle* h, int32_t channel, const msk144_candidate* items)
 {
     if(!h || !items || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
-    if(h->llr_block < h->st.channels) return fail(h, MSK144_ENOTRETAINED, "blocked staging cannot take loaded candidates; create the handle with llr_block_channels = channels");
+    if(!h->retained) return fail(h, MSK144_ENOTRETAINED, "a handle that does not retain its LLR rows cannot take loaded candidates; create the handle with llr_block_channels = channels");
     int rc = msk144_synchronize(h);
     if(rc != MSK144_OK) return rc;
     const DeviceStore& st = h->st;

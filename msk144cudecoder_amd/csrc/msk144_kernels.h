@@ -39,6 +39,10 @@ struct DeviceStore
     // LLR rows do not outlive their block (the handle's block is smaller than its channel capacity): a candidate the nbadsync
     // gate is going to drop is not demodulated beyond its sync check (softbits_kernel<true>)
     int32_t gate_early;
+    // Copies handed over (only with gate_early; msk144_set_copy_handover): a slot whose position folds the same frames as a LOWER slot
+    // of its (frequency, pattern) group is not demodulated or decoded, it reports that slot's result.  0: every slot is computed on its
+    // own, as the reference does (softbits_kernel.cuh:56-83, ldpc_kernel.cuh:100-249)
+    int32_t handover;
 
     const float* freq;        // [F] Hz, host-computed as msk_context.cuh:135
     const float2* cb42;       // [42] sync template (re, im), for kernels that index it per lane
@@ -57,6 +61,7 @@ struct DeviceStore
     uint32_t* dec_msg;        // [channels][K][3]  77 bits MSB first in 96
 
     int32_t* dec_count;       // [channels] decodes per channel
+    int32_t* copy_count;      // [channels] slots of the last decode that were handed to a lower slot (collect stage)
     int32_t* result_count;    // [1]
     void* results;            // [max_results] msk144_result
 };

@@ -484,16 +484,23 @@ void launch_scan(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t str
     a.stamps = stamp_buffer(0);
 #endif
     const dim3 grid(a.tiles_per_xcd * 8), block(kScanThreads);
+#ifdef MSK144_SCAN_LDS_PAD_BYTES
+    // occupancy probe only (tools/ab_variants.py, DESIGN.md 4.3: what a fused scan -> softbits tile that keeps the mixed window beside C
+    // would cost in resident workgroups): unused dynamic LDS that limits a CU to two (+15 KB) or one (+42 KB) workgroups.  Never in the product build.
+    constexpr size_t kDynLds = MSK144_SCAN_LDS_PAD_BYTES;
+#else
+    constexpr size_t kDynLds = 0;
+#endif
     switch(st.D)
     {
-    case 1: hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(scan_kernel<2>, grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(scan_kernel<3>, grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL(scan_kernel<5>, grid, block, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL(scan_kernel<6>, grid, block, 0, stream, a); break;
-    case 7: hipLaunchKernelGGL(scan_kernel<7>, grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL(scan_kernel<8>, grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL(scan_kernel<1>, grid, block, kDynLds, stream, a); break;
+    case 2: hipLaunchKernelGGL(scan_kernel<2>, grid, block, kDynLds, stream, a); break;
+    case 3: hipLaunchKernelGGL(scan_kernel<3>, grid, block, kDynLds, stream, a); break;
+    case 4: hipLaunchKernelGGL(scan_kernel<4>, grid, block, kDynLds, stream, a); break;
+    case 5: hipLaunchKernelGGL(scan_kernel<5>, grid, block, kDynLds, stream, a); break;
+    case 6: hipLaunchKernelGGL(scan_kernel<6>, grid, block, kDynLds, stream, a); break;
+    case 7: hipLaunchKernelGGL(scan_kernel<7>, grid, block, kDynLds, stream, a); break;
+    default: hipLaunchKernelGGL(scan_kernel<8>, grid, block, kDynLds, stream, a); break;
     }
 }
 

@@ -186,7 +186,8 @@ __device__ __forceinline__ void filter_group(const v2f (&x)[kGroup], const float
 // kGateEarly: blocked staging keeps no LLR row of a candidate the index stage will drop (nbadsync > threshold), so such a
 // candidate stops after its sync check - a third of the noise candidates at threshold 3.  With the LLR store retained
 // (llr_block_channels = channels: dumps, parity tests) every candidate is demodulated in full, as in the reference.
-template<bool kGateEarly>
+// kHandOver (only with kGateEarly): slots that fold the same frames as a lower slot of their group are handed to it (below).
+template<bool kGateEarly, bool kHandOver>
 __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsArgs a)
 {
     __shared__ __attribute__((aligned(16))) float2 s_x[kWindowSamples + kRingPad + 3];
@@ -255,8 +256,9 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     // leaves it out and the collect stage gives it the nbadsync and the decode of the slot it names (index.hip).  With the store
     // retained every slot is computed on its own, as in the reference.
     // Bit 8 i + s of same_frames: slot s of pattern i is congruent to THIS wave's slot of pattern i.
+    static_assert(kGateEarly || !kHandOver, "a retained LLR store keeps every slot's own row");
     uint64_t same_frames = 0;
-    if(kGateEarly)
+    if(kHandOver)
     {
         uint32_t r = pos_of_lane >= static_cast<uint32_t>(kWindowSamples) ? pos_of_lane - kWindowSamples : pos_of_lane;
         const int pattern_of_lane = lane >> 3;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
         const size_t item = item0 + c;
         uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), c));
         if(pos >= static_cast<uint32_t>(kWindowSamples)) pos -= kWindowSamples;  // scanned positions reach 5375
-        if(kGateEarly)
+        if(kHandOver)
         {
             // a lower slot of this (frequency, pattern) group folds the same frames: it does the work, this slot names it
             const uint32_t lower = static_cast<uint32_t>(same_frames >> (kSlotsPerPattern * i)) & ((1u << wave) - 1u);
@@ -478,8 +480,9 @@ void launch_softbits(const DeviceStore& st, const SyncTemplate& tpl, hipStream_t
 #endif
     const int grid = a.tiles_per_xcd * 8;
     // LLR rows are retained only when one block covers every channel of the handle (msk144_api.cpp: dumps, parity tests)
-    if(st.gate_early) hipLaunchKernelGGL(softbits_kernel<true>, dim3(grid), dim3(kSbThreads), 0, stream, a);
-    else hipLaunchKernelGGL(softbits_kernel<false>, dim3(grid), dim3(kSbThreads), 0, stream, a);
+    if(st.gate_early && st.handover) hipLaunchKernelGGL((softbits_kernel<true, true>), dim3(grid), dim3(kSbThreads), 0, stream, a);
+    else if(st.gate_early) hipLaunchKernelGGL((softbits_kernel<true, false>), dim3(grid), dim3(kSbThreads), 0, stream, a);
+    else hipLaunchKernelGGL((softbits_kernel<false, false>), dim3(grid), dim3(kSbThreads), 0, stream, a);
 }
 
 }  // namespace msk144

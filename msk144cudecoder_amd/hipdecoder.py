@@ -28,7 +28,8 @@ ABI_SYMBOLS = (
     "msk144_result_count", "msk144_results_device", "msk144_set_channel_base", "msk144_segment_power", "msk144_dump_analytic", "msk144_dump_candidates",
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
     "msk144_input_slot", "msk144_submit_slot", "msk144_submit_slot_n", "msk144_fetch_async", "msk144_fetch_wait", "msk144_hop_slot", "msk144_push_hops",
-    "msk144_device_count", "msk144_clock_probe",
+    "msk144_device_count", "msk144_clock_probe", "msk144_set_copy_handover", "msk144_copy_handover", "msk144_copy_count",
+    "msk144_set_llr_retention",
 )
 
 
@@ -111,6 +112,10 @@ def load_library(path: Optional[str] = None):
     L.msk144_fetch_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp)]
     L.msk144_device_count.argtypes = [C.POINTER(i32)]
     L.msk144_clock_probe.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    L.msk144_set_copy_handover.argtypes = [vp, i32]
+    L.msk144_set_llr_retention.argtypes = [vp, i32]
+    L.msk144_copy_handover.argtypes = [vp, C.POINTER(i32)]
+    L.msk144_copy_count.argtypes = [vp, C.POINTER(C.c_int64)]
     if path is None:
         _lib = L
     return L
@@ -220,6 +225,27 @@ class HipDecoder:
     def set_channel_base(self, base: int):
         """Result records carry channel = base + local channel (global ids for the multi-GPU gather)."""
         self._chk(self.L.msk144_set_channel_base(self.h, base))
+
+    def set_llr_retention(self, retain: bool):
+        """A one-block handle (llr_block_channels = channels) keeps every LLR row readable (dumps).  retain=False: behave like a
+        blocked handle - early nbadsync gate, copies handed over, dumps refused (what msk144hipdecoder asks for)."""
+        self._chk(self.L.msk144_set_llr_retention(self.h, 1 if retain else 0))
+
+    def set_copy_handover(self, on: bool):
+        """Blocked staging only: whether a slot that folds the same frames as a lower slot of its group reports that slot's result
+        (default) or is demodulated and decoded on its own, as the reference does."""
+        self._chk(self.L.msk144_set_copy_handover(self.h, 1 if on else 0))
+
+    def copy_handover(self) -> bool:
+        v = C.c_int32()
+        self._chk(self.L.msk144_copy_handover(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def copy_count(self) -> int:
+        """Slots of the last decode that were handed to a lower slot of their group."""
+        v = C.c_int64()
+        self._chk(self.L.msk144_copy_count(self.h, C.byref(v)))
+        return int(v.value)
 
     def segment_power(self) -> np.ndarray:
         out = np.empty((self.channels, 8), dtype=np.float32)

@@ -62,6 +62,7 @@ void show_help(const char* prog)
     std::cout << "                   --device=N                  HIP device ordinal. Default=0." << std::endl;
     std::cout << "                   --devices=N1,N2,...|all     With --inputs/--interleaved: split the streams contiguously over these devices; each device gets its own ingest and post-processing threads, ch=<index> stays the global stream number. An ordinal may repeat (two independent loops on one GPU)." << std::endl;
     std::cout << "                   --max-results=N             Capacity of the per-hop decode list of a device (default 256 per stream + 131072). A hop that exceeds it is cut and reported; decoding goes on." << std::endl;
+    std::cout << "                   --every-slot                Demodulate and decode every candidate slot on its own, as the reference does. Default off: a slot whose position folds the same frames as a lower slot of its group reports that slot's result (same output), and a candidate the nbadsync gate drops is not demodulated beyond its sync check." << std::endl;
     std::cout << "                   --timing                    With --inputs: per-hop host and device time split (ingest, H2D, GPU, D2H, post-processing) on stderr at the end." << std::endl;
     // clang-format on
 }
@@ -164,6 +165,7 @@ int main(int argc, char* const argv[])
                                            {"interleaved", required_argument, 0, 0},
                                            {"devices", required_argument, 0, 0},
                                            {"max-results", required_argument, 0, 0},
+                                           {"every-slot", no_argument, 0, 0},
                                            {0, 0, 0, 0}};
     while(true)
     {
@@ -205,6 +207,7 @@ int main(int argc, char* const argv[])
         case 18: interleaved = atoi(optarg); break;
         case 19: split_list(optarg, device_list); break;
         case 20: opt.max_results = atoi(optarg); break;
+        case 21: opt.every_slot = true; break;
         default: show_help(argv[0]); return 0;
         }
     }

@@ -33,6 +33,11 @@ WindowDecoder::WindowDecoder(const DecoderOptions& opt)
         handle_ = nullptr;
         return;
     }
+    // The program reads the result list only: no LLR row has to outlive its decode, whatever the number of streams - the kernels
+    // then stop a candidate the nbadsync gate drops after its sync check and compute slots that fold the same frames once
+    // (include/msk144hip.h), exactly as a large batch does.  --every-slot: every slot on its own, as in the reference.
+    msk144_set_llr_retention(handle_, 0);
+    if(opt.every_slot) msk144_set_copy_handover(handle_, 0);
     msk144_geometry(handle_, &F_, &D_, &K_);
     snr_.resize(opt_.channels);
     filter_.resize(opt_.channels);

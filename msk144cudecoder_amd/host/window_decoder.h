@@ -35,6 +35,10 @@ struct DecoderOptions
     bool print_bits = false;  // append the 77-bit payload to each line (debug)
     bool profile = false;     // record per-stage device times (HIP events; --timing)
     int max_results = 0;      // --max-results: capacity of the compact decode list per hop; 0 = 256 per stream + 131072
+    // --every-slot: demodulate and decode every slot on its own as the reference does (softbits_kernel.cuh:56-83, ldpc_kernel.cuh:100-249).
+    // Default: the program only reads the result list, so no LLR row has to outlive its decode (msk144_set_llr_retention(h, 0)) and
+    // slots that fold the same frames as a lower slot of their group report that slot's result - the same list (include/msk144hip.h)
+    bool every_slot = false;
 };
 
 // Host wall time of one hop, split the way the pipelined loop spends it.

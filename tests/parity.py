@@ -72,6 +72,17 @@ def bp_marginal_limit(decodes: int) -> int:
     return count_limit(BP_MARGINAL_RATE, decodes)
 
 
+def handed_over_records(dec, records):
+    """Mask over `records` (the result list `dec` has just decoded with copies handed over): True where the record's slot was NOT in its
+    channel's index list, i.e. it was never demodulated or decoded itself and reports the result of a lower slot of its group
+    (csrc/softbits.hip, index.hip).  Reads the index lists of the channels that have records; call before the next decode."""
+    mask = np.zeros(len(records), dtype=bool)
+    for ch in np.unique(records["channel"]):          # channel base 0: record channels are the handle's channels
+        sel = np.nonzero(records["channel"] == ch)[0]
+        mask[sel] = ~np.isin(records["item"][sel], dec.dump_indexes(int(ch)))
+    return mask
+
+
 def copy_class(items, k):
     """Slots of one (frequency, pattern) group that fold the same frames - ring-wrap twins, the periodic copies of masks 111111 / 100100 -
     are one event when something marginal happens to them: (block, pattern, position modulo the ring and the pattern's period)."""

@@ -123,6 +123,8 @@ int msk144_frequency(const msk144_handle* h, int32_t b, float* hz)
 }
 
 int msk144_set_profiling(msk144_handle*, int32_t) { return MSK144_OK; }
+int msk144_set_llr_retention(msk144_handle*, int32_t) { return MSK144_OK; }
+int msk144_set_copy_handover(msk144_handle*, int32_t) { return MSK144_OK; }
 
 int msk144_stage_times(msk144_handle*, float* ms, int32_t*, int32_t)
 {

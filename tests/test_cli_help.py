@@ -16,5 +16,5 @@ def test_help_text_is_the_references_verbatim():
     want = [l.replace("{prog}", EXE) for l in ref]
     assert lines[:len(want)] == want
     extra = "\n".join(lines[len(want):])
-    for flag in ("--inputs=", "--inputs-file=", "--interleaved=", "--connect-timeout-ms=", "--timing", "--hop-timeout-ms=", "--skip-wav-header", "--reference-decode-cache", "--strict-decode", "--print-bits", "--device="):
+    for flag in ("--inputs=", "--inputs-file=", "--interleaved=", "--connect-timeout-ms=", "--timing", "--hop-timeout-ms=", "--skip-wav-header", "--reference-decode-cache", "--strict-decode", "--print-bits", "--device=", "--every-slot", "--max-results="):
         assert flag in extra

@@ -33,6 +33,12 @@ def test_launcher_line_matches_the_plain_run():
         assert line["config"]["softbits_gate_early"] is True and line["config"]["llr_store"] == "blocked/64"
         assert line["roofline"]["kernel"] == "ldpc_kernel" and 0.0 < line["roofline"]["frac"] < 1.0
         assert line["rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])
+        # `value` counts reported slots; the line says how many were handed over and carries the every-slot figure beside it
+        ho, every = line["copy_handover"], line["value_every_slot_decoded"]
+        assert ho["enabled"] is True and 0.10 < ho["share_of_slots"] < 0.20 and line["config"]["copies_computed_once"] is True
+        assert every["slots_handed_over"] == 0 and every["records_last_step"] > 0
+        assert 0.80 < every["value"] / line["value"] < 0.97, (every["value"], line["value"])
+        assert f"{100.0 * ho['share_of_slots']:.1f} %" in line["config"]["value_counts"]
 
 
 def test_distributed_line_carries_the_cpu_baseline():

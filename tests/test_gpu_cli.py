@@ -49,6 +49,10 @@ def _both_modes(orc, args, stream, cfg, read_mode=1):
     assert strict == _expected_lines(orc, stream, cfg, read_mode, quirk=False)
     rc, out_c, _ = _run(args + ["--reference-decode-cache"], stream.tobytes())
     assert rc == 0 and _lines(out_c) == got
+    # the default run hands copies to the lower slot of their group and gates before the full demodulation (the kernels bench.py times);
+    # --every-slot computes each slot on its own as the reference does: the same stdout
+    rc, out_e, err_e = _run(args + ["--every-slot"], stream.tobytes())
+    assert rc == 0 and _lines(out_e) == got, err_e
     return got, strict, err
 
 

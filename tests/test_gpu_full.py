@@ -64,7 +64,13 @@ def test_1024_channel_batch_properties(orc, hip, parity_report):
         dp.submit_audio(wins[2])
         dp.decode()
         prod = dp.results().copy()
+        handed = parity.handed_over_records(dp, prod)
+        handed_slots = dp.copy_count()
     assert prod.tobytes() == res1.tobytes()
+    # records whose slot was never computed itself (its lower slot's result, its own pos / xb): each one equals the record the
+    # retained handle computed for that very slot
+    assert handed.sum() > 1000 and prod[handed].tobytes() == res1[handed].tobytes()
+    assert 0.10 < handed_slots / (1024 * 24048) < 0.20
     key = res1["channel"].astype(np.int64) * 100000 + res1["item"]
     assert np.all(np.diff(key) > 0)                                     # ordered by (channel, item)
     decoded_channels = set(int(c) for c in np.unique(res1["channel"]))
@@ -97,6 +103,10 @@ def test_1024_channel_batch_properties(orc, hip, parity_report):
             dumps[ch] = d1.dump_candidates(0)                           # single == batch bit for bit (asserted above)
     report = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_audio(wins[2, ch], 2) for ch in sample}, dumps)
     assert report["channels"] == 16 and report["decodes"] >= 8, report
+    report["handed_over_records"] = int(handed.sum())
+    report["handed_over_records_differing_from_their_own_decode"] = 0
+    report["records"] = int(len(prod))
+    report["handed_over_slots_share"] = handed_slots / (1024 * 24048)
     parity_report("production_path_1024ch_vs_oracle", report)
 
 
@@ -151,7 +161,10 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
         dp.submit_iq(wins)
         dp.decode()
         prod = dp.results().copy()
+        handed = parity.handed_over_records(dp, prod)
+        handed_slots = dp.copy_count()
     assert prod.tobytes() == res1.tobytes()
+    assert handed.sum() > 1000 and prod[handed].tobytes() == res1[handed].tobytes()      # slots never computed themselves = their own decode
     key = res1["channel"].astype(np.int64) * 100000 + res1["item"]
     assert np.all(np.diff(key) > 0)                                     # ordered by (channel, item)
     good = {int(r["channel"]) for r in res1 if truth.get(int(r["channel"])) == bytes(r["message"])}
@@ -192,6 +205,10 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
             dumps[ch] = d1.dump_candidates(0)
     direct = parity.compare_result_list_with_oracle(o, orc, prod, {ch: o.frontend_iq(wins[ch]) for ch in sample}, dumps)
     assert direct["channels"] == 16 and direct["decodes"] >= 8, direct
+    direct["handed_over_records"] = int(handed.sum())
+    direct["handed_over_records_differing_from_their_own_decode"] = 0
+    direct["records"] = int(len(prod))
+    direct["handed_over_slots_share"] = handed_slots / (nch * 24048)
     parity_report("production_path_config4_vs_oracle", direct)
     parity_report("config4_iq_4096", dict(channels=nch, decodes=int(len(res1)), pinged=len(truth), pinged_decoded=len(good),
                                           not_transmitted=len(unexpected), channel0=dict(scan=rep, softbits=sb, ldpc=ld)))
@@ -244,12 +261,30 @@ def test_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
         full = d.results().copy()
         items = [d.dump_candidates(c) for c in range(2)]
         idx_full = [d.dump_indexes(c) for c in range(2)]
+        assert d.copy_handover() is False and d.copy_count() == 0
+        with pytest.raises(hip.Msk144Error) as e:        # a handle that retains every row never hands a slot over
+            d.set_copy_handover(True)
+        assert e.value.code == -6
+        d.set_copy_handover(False)
     with hip.HipDecoder(channels=2, llr_block_channels=1, max_results=1 << 18, **cfg) as d:
         d.submit_audio(wins)
         d.decode()
         blocked = d.results().copy()
         idx_blocked = [d.dump_indexes(c) for c in range(2)]
+        assert d.copy_handover() is True
+        copies_counted = d.copy_count()
+        # (4) the switch: blocked staging WITHOUT the hand-over computes every slot, as the reference does
+        d.set_copy_handover(False)
+        d.submit_audio(wins)
+        d.decode()
+        every_slot = d.results().copy()
+        idx_every_slot = [d.dump_indexes(c) for c in range(2)]
+        assert d.copy_count() == 0 and d.copy_handover() is False
+        d.set_copy_handover(True)
+        d.decode()
+        assert d.results().tobytes() == blocked.tobytes() and d.copy_count() == copies_counted
     assert blocked.tobytes() == full.tobytes() and len(full) > 20                                    # (3)
+    assert every_slot.tobytes() == full.tobytes()
     period = {5: 864, 6: 2592}
     handed = kept = 0
     accepted_copies = 0
@@ -263,6 +298,8 @@ def test_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
                 drop[g0 + sl] = bool((r[:sl] == r[sl]).any())
         want = np.array([k for k in idx_full[c] if not drop[k]], dtype=np.int32)
         assert np.array_equal(idx_blocked[c], want), c                                                # (1)
+        assert np.array_equal(idx_every_slot[c], idx_full[c]), c                                      # (4): the retained index list exactly
+        copies_counted -= int(drop.sum())
         handed += int(drop[idx_full[c]].sum())
         kept += len(want)
         five = it["pattern_idx"] == 5
@@ -270,8 +307,40 @@ def test_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
         assert drop[five].mean() > 0.5 and 0.0 < drop[wrap_only].mean() < 0.08                        # (2)
         accepted_copies += int((drop & (it["is_message_present"] == 1)).sum())
     assert accepted_copies >= 1            # the list identity above covered records that were never decoded themselves
+    assert copies_counted == 0             # msk144_copy_count = the slots with a congruent lower slot, gated or not
     parity_report(f"copies_handed_over_depth{depth}", dict(gated_slots_handed_over=handed, gated_slots_decoded=kept, accepted_copies_in_the_result_list=accepted_copies,
                                                            result_lists_identical=True))
+
+
+def test_handed_over_records_equal_their_own_decode(hip, parity_report):
+    """The four 1024-channel windows bench.py cycles through, production path (64-channel blocks, copies handed over) against the same
+    handle with the hand-over switched off (every slot demodulated and decoded on its own, as the reference does): lists byte-identical,
+    and the records whose slot was handed over - never computed themselves - are counted and compared on their own."""
+    import bench
+    wins, _ = bench.make_inputs(0, 1024)
+    tot = dict(windows=0, records=0, handed_over_records=0, handed_over_records_differing_from_their_own_decode=0, handed_over_slots=0, slots=0)
+    with hip.HipDecoder(channels=1024, max_results=1 << 20, **DEEP) as d:
+        for t in range(wins.shape[0]):
+            d.set_copy_handover(True)
+            d.submit_audio(wins[t])
+            d.decode()
+            prod = d.results().copy()
+            handed = parity.handed_over_records(d, prod)
+            tot["handed_over_slots"] += d.copy_count()
+            d.set_copy_handover(False)
+            d.decode()
+            own = d.results().copy()
+            assert d.copy_count() == 0
+            assert len(own) == len(prod)
+            tot["windows"] += 1
+            tot["records"] += len(prod)
+            tot["slots"] += 1024 * d.K
+            tot["handed_over_records"] += int(handed.sum())
+            tot["handed_over_records_differing_from_their_own_decode"] += int(np.count_nonzero(prod[handed] != own[handed]))
+            assert prod.tobytes() == own.tobytes(), t
+    assert tot["handed_over_records"] > 5000 and tot["handed_over_records_differing_from_their_own_decode"] == 0, tot
+    assert 0.10 < tot["handed_over_slots"] / tot["slots"] < 0.20, tot
+    parity_report("handed_over_records_4_bench_windows", tot)
 
 
 def test_silent_and_saturated_channels_in_a_blocked_batch(hip):

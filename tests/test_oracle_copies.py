@@ -3,28 +3,28 @@
 Two slots of one (frequency, pattern) group whose positions are congruent modulo the ring (5184: the scan walks 5376 positions) or, for masks
 111111 / 100100, modulo 864 / 2592 fold the same frames (softbits_kernel.cuh:56-83).  The reference demodulates and decodes both; the HIP
 path, in blocked staging, computes the lower slot and lets the copy report its result (msk144cudecoder_amd/csrc/softbits.hip, index.hip;
-DESIGN.md 3).  That is exact for ring-wrap twins (the same computation) and exact up to float association for periodic copies.  Here the
-oracle computes EVERY slot on its own, as the reference does, and the test counts how often a copy's own result differs from its lower
-slot's: never, on these windows - the quantity the GPU soak (tests/soak_list_identity.py) measures on the kernels."""
+DESIGN.md 3; msk144_set_copy_handover switches it off).  That is exact for ring-wrap twins (the same computation) and exact up to float
+association for periodic copies.  Here the oracle computes EVERY slot on its own, as the reference does, and the test counts how often a
+copy's own result differs from its lower slot's: never, on these windows.  tests/soak_oracle_copies.py is the same comparison over
+thousands of windows (profiles/r06_oracle_copy_soak.json: the measured rate and its bound); tests/soak_list_identity.py measures it on the kernels."""
 import numpy as np
 import pytest
 
 from msk144cudecoder_amd import synth
 
-PERIOD = {5: 864, 6: 2592}
+import soak_oracle_copies as soak
 
 
-def _copies(items):
-    """[(copy item, lower item)] per the rule of softbits_kernel<true>: lowest slot of the group with the same residue."""
-    pos = items["pos"].astype(np.int64) % 5184
-    out = []
-    for g0 in range(0, len(items), 8):
-        r = pos[g0:g0 + 8] % PERIOD.get(int(items["pattern_idx"][g0]), 5184)
-        for sl in range(1, 8):
-            same = np.nonzero(r[:sl] == r[sl])[0]
-            if len(same):
-                out.append((g0 + sl, g0 + int(same[0])))
-    return out
+def test_pairing_rule_on_a_handmade_group():
+    """copy_pairs = the rule of softbits_kernel<true, true>: lowest congruent slot of the group; twin vs periodic."""
+    items = np.zeros(16, dtype=[("pos", "<u4"), ("pattern_idx", "<u4")])
+    items["pattern_idx"][:8] = 2
+    items["pos"][:8] = [10, 5194, 11, 10, 900, 5184 + 900, 7, 8]          # slot 1 and 3 are twins of 0, slot 5 of 4 (mod 5184 only)
+    items["pattern_idx"][8:] = 5
+    items["pos"][8:] = [100, 964, 100 + 5184, 101, 1828, 965, 99, 963]      # mod 864: 100 100 100 101 100 101 99 99
+    c, l, per = soak.copy_pairs(items)
+    got = sorted(zip(c.tolist(), l.tolist(), per.tolist()))
+    assert got == [(1, 0, False), (3, 0, False), (5, 4, False), (9, 8, True), (10, 8, False), (12, 8, True), (13, 11, True), (15, 14, True)]
 
 
 @pytest.mark.parametrize("depth,width,seed", [(6, 160.0, 1), (6, 160.0, 2), (8, 60.0, 3)])
@@ -36,31 +36,17 @@ def test_a_copy_decodes_like_its_lower_slot(orc, depth, width, seed):
     x = synth.synth_audio(5184, pings, 1000.0, rng)
     o = orc.Oracle(threads=8, **cfg)
     items, _ = o.decode_window(o.frontend_audio(x, 2))
-    pairs = _copies(items)
+    c, l, per = soak.copy_pairs(items)
     five = items["pattern_idx"] == 5
-    n_five_copies = sum(1 for c, _ in pairs if items["pattern_idx"][c] == 5)
-    assert n_five_copies > 0.5 * int(five.sum())                       # most slots of mask 111111 are copies
-    assert any(items["pattern_idx"][c] < 5 for c, _ in pairs)            # and a few ring-wrap twins elsewhere
-    differ = dict(nbadsync=0, accept=0, iterations=0, hard_errors=0, payload=0, llr_max_rel=0.0)
-    accepted_copies = 0
-    for c, l in pairs:
-        a, b = items[c], items[l]
-        differ["nbadsync"] += int(a["nbadsync"] != b["nbadsync"])
-        if a["nbadsync"] != b["nbadsync"]:
-            continue
-        d = np.abs(a["softbits_wo_sync"].astype(np.float64) - b["softbits_wo_sync"]) / np.maximum(1.0, np.abs(b["softbits_wo_sync"]))
-        if np.isfinite(d).all():
-            differ["llr_max_rel"] = max(differ["llr_max_rel"], float(d.max()))
-        if a["nbadsync"] > cfg["nbadsync_threshold"]:
-            continue
-        differ["accept"] += int(a["is_message_present"] != b["is_message_present"])
-        if a["is_message_present"] and b["is_message_present"]:
-            accepted_copies += 1
-            differ["iterations"] += int(a["ldpc_num_iterations"] != b["ldpc_num_iterations"])
-            differ["hard_errors"] += int(a["ldpc_num_hard_errors"] != b["ldpc_num_hard_errors"])
-            differ["payload"] += int(not np.array_equal(a["message"], b["message"]))
+    assert int((items["pattern_idx"][c] == 5).sum()) > 0.5 * int(five.sum())     # most slots of mask 111111 are copies
+    assert (items["pattern_idx"][c] < 5).any()                                  # and a few ring-wrap twins elsewhere
+    twins = soak.compare_pairs(items, c[~per], l[~per], 3)
+    copies = soak.compare_pairs(items, c[per], l[per], 3)
     # ring-wrap twins are the same computation; periodic copies add the same frames in another order: LLRs within a few ulp
-    assert differ["llr_max_rel"] < 1e-5, differ
-    assert differ["nbadsync"] == 0 and differ["accept"] == 0 and differ["iterations"] == 0 and differ["hard_errors"] == 0 and differ["payload"] == 0, differ
+    assert twins["llr_max_rel"] == 0.0 and copies["llr_max_rel"] < 1e-5, (twins, copies)
+    for r in (twins, copies):
+        assert r["pairs"] > 0 and r["both_gated"] > 0
+        assert all(r[k] == 0 for k in ("nbadsync_differs", "gate_differs", "accept_differs", "iterations_differ", "hard_errors_differ", "payload_differs",
+                                       "reported_record_differs")), r
     if pings:
-        assert accepted_copies >= 1                                      # the ping's copies decode, like their lower slots
+        assert twins["both_accepted"] + copies["both_accepted"] >= 1             # the ping's copies decode, like their lower slots
