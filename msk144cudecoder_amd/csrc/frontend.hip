@@ -5,7 +5,8 @@
 //                    <<<1,32>>> (analytic2.cuh:235-258), D2H for the SNR tracker (main.cu:327)
 //   IQ:              host int8->complex (main.cu:365-371), apply_filter<<<1,32>>> (analytic2.cuh:260-281)
 //   audio, method 1: Analytic::execute (analytic_fft.cu:84-157): scale, cuFFT forward, D2H, host mask,
-//                    H2D, cuFFT inverse, D2H, H2D  ->  one 8192-point radix-2 FFT pair in LDS
+//                    H2D, cuFFT inverse, D2H, H2D  ->  one 8192-point transform pair in LDS, 16 x 16 x 32 mixed radix with
+//                    register-resident butterflies and the spectral mask applied between them (frontend_fft_kernel below)
 // plus the 8 segment powers SNRTracker::process_data needs (snr_tracker.cu:21-37), so the analytic
 // window never has to travel back to the host.
 //
