@@ -442,8 +442,9 @@ def parse_args(argv=None):
                     help="after the K timed steps, keep running the same step for about this long (untimed inputs unchanged) and report the step time of its "
                          "first / middle / last 50 steps and the shader clock: `value` stays the K-step figure (0 = skip)")
     ap.add_argument("--no-extra-legs", action="store_true",
-                    help="skip the short legs a single-GPU run appends after the timed region: value_incl_h2d (pinned host windows), frontend_method1 "
-                         "(FFT front end beside the FIR one) and configs4_iq (BASELINE configs[4])")
+                    help="skip the short legs appended after the timed region: value_every_slot_decoded (the same step with the copy hand-over off; every rank "
+                         "runs it) and, single-GPU runs only, value_incl_h2d (pinned host windows), frontend_method1 (FFT front end beside the FIR one) and "
+                         "configs4_iq (BASELINE configs[4])")
     ap.add_argument("--launcher", action="store_true", help="go through the N-rank launcher even for --gpus 1 (exercises the RCCL gather path)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend-module", default=None, help="TEST HOOK: module providing Backend (e.g. tests/stub_backend.py on gloo); the line is then labelled as such")
@@ -595,7 +596,7 @@ def run_worker(args) -> int:
         on = be.dec.copy_handover()
         handed = be.dec.copy_count()
         handover = {"enabled": on, "slots_handed_over_last_step": handed, "share_of_slots": handed / cand_per_step}
-        if on:
+        if on and not args.no_extra_legs:
             handover["value_every_slot_decoded"] = every_slot_leg(be, max(4, min(args.steps, 10)), args.warmup + args.steps)
     # Short extra legs, single-GPU runs of the product backend only (each on rank 0 would leave the other ranks waiting): after
     # everything the main line reports has been read, so they cannot disturb it.

@@ -94,19 +94,6 @@ struct msk144_handle
     hipStream_t probe_stream = nullptr;
     uint64_t* d_probe = nullptr;
 
-    // EXPERIMENT (msk144_set_graph_replay): the launches of one full decode captured once per launch shape and replayed
-    struct GraphKey
-    {
-        int active, slot_records, channel_base, handover, gate_early;
-        hipStream_t stream;
-        bool operator==(const GraphKey& o) const
-        {
-            return active == o.active && slot_records == o.slot_records && channel_base == o.channel_base && handover == o.handover && gate_early == o.gate_early && stream == o.stream;
-        }
-    };
-    bool graph_replay = false;
-    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
-
     std::string error;
 };
 
@@ -543,7 +530,6 @@ void msk144_destroy(msk144_handle* h)
         (void)hipEventDestroy(sp.e0);
         (void)hipEventDestroy(sp.e1);
     }
-    for(auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
     for(hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if(h->ev_open) (void)hipEventDestroy(h->ev_open);
     if(h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -635,45 +621,7 @@ int msk144_submit_analytic(msk144_handle* h, const float* windows)
     return MSK144_OK;
 }
 
-static int launch_stages(msk144_handle* h, uint32_t stages);
-
-int msk144_set_graph_replay(msk144_handle* h, int32_t enable)
-{
-    if(!h) return MSK144_EINVAL;
-    h->graph_replay = enable != 0;
-    return MSK144_OK;
-}
-
 int msk144_decode_stages(msk144_handle* h, uint32_t stages)
-{
-    if(h && h->graph_replay && stages == MSK144_STAGE_ALL && !h->profiling && h->have_window)
-    {
-        HIP_TRY(h, hipSetDevice(h->params.device));
-        const msk144_handle::GraphKey key{h->active, h->slots_ready ? h->cur_slot : -1, h->st.channel_base, h->st.handover, h->st.gate_early, h->stream};
-        hipGraphExec_t exec = nullptr;
-        for(auto& g : h->graphs)
-            if(g.first == key) exec = g.second;
-        if(!exec)
-        {
-            hipGraph_t graph = nullptr;
-            HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = launch_stages(h, stages);
-            const hipError_t e = hipStreamEndCapture(h->stream, &graph);
-            if(rc != MSK144_OK) return rc;
-            if(e != hipSuccess) return fail(h, MSK144_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            HIP_TRY(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            h->graphs.emplace_back(key, exec);
-        }
-        h->call_id++;
-        HIP_TRY(h, hipGraphLaunch(exec, h->stream));
-        h->decoded = true;
-        return MSK144_OK;
-    }
-    return launch_stages(h, stages);
-}
-
-static int launch_stages(msk144_handle* h, uint32_t stages)
 {
     if(!h) return MSK144_EINVAL;
     if((stages & (MSK144_STAGE_SCAN | MSK144_STAGE_SOFTBITS)) && !h->have_window) return fail(h, MSK144_ESTATE, "decode before any window was submitted");

@@ -320,29 +320,9 @@ __global__ __launch_bounds__(kSbThreads, 6) void softbits_kernel(const SoftbitsA
     for(int k = 0; k < 8; k++)
         if(lane == k || lane == kSecondSyncBit + k) sync_pm = kSync8Pm[k];
 
-#ifdef MSK144_SB_REDEAL
-    // EXPERIMENT: with copies handed over wave 0 (slot 0 of every pattern: never a copy) always folds the six-frame candidate of mask
-    // 111111, which the other waves mostly skip (73 % of its slots are copies; the higher the slot, the likelier).  Wave 0 leaves its
-    // (pattern 1, slot 0) candidate to wave 7, the least loaded one, which takes it after its own.
-    const bool redeal = kHandOver && D > kFirstPeriodicPattern;
-    const int n_iter = redeal ? D + 1 : D;
-#else
-    constexpr bool redeal = false;
-    const int n_iter = D;
-#endif
-    for(int i = 0; i < n_iter; i++)
+    for(int i = 0; i < D; i++)
     {
-        int p = i, slot = wave;
-        if(redeal)
-        {
-            if(i == 1 && wave == 0) continue;
-            if(i == D)
-            {
-                if(wave != kSbWaves - 1) break;
-                p = 1;
-                slot = 0;
-            }
-        }
+        const int p = i, slot = wave;  // wave w owns slot w of every pattern
         const int c = slot + kSbWaves * p;
         const size_t item = item0 + c;
         uint32_t pos = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pos_of_lane), c));

@@ -312,6 +312,42 @@ def test_copies_are_handed_to_the_lower_slot(hip, parity_report, depth, width):
                                                            result_lists_identical=True))
 
 
+def test_single_stream_handle_without_llr_retention(hip):
+    """msk144_set_llr_retention(h, 0) - what msk144hipdecoder asks of every handle, its single stream included: a one-block handle then
+    runs the kernels of a blocked batch (early nbadsync gate, copies handed over).  Same result list as the retaining handle, dumps and
+    partial stage runs refused until retention is switched back on."""
+    cfg = dict(center=1500.0, width=200.0, step=1.0, depth=6, nbadsync_threshold=3)
+    rng = np.random.default_rng(515)
+    x = synth.synth_audio(5184, [synth.Ping(synth.random_message(rng), 100, 6, 1500.0 - 61.7, 3.0, 2.1)], 1000.0, rng)
+    with hip.HipDecoder(channels=1, max_results=1 << 16, **cfg) as d:
+        d.submit_audio(x)
+        d.decode()
+        want = d.results().copy()
+        idx_all = d.dump_indexes(0)
+        d.set_llr_retention(False)
+        assert d.copy_handover() is True
+        d.decode()
+        assert d.results().tobytes() == want.tobytes() and len(want) > 20
+        assert d.copy_count() > 0 and len(d.dump_indexes(0)) < len(idx_all)
+        for call in (lambda: d.dump_candidates(0), lambda: d.decode(hip.STAGE_LDPC), lambda: d.load_candidates(np.zeros(d.K, dtype=hip.CANDIDATE_DTYPE))):
+            with pytest.raises(hip.Msk144Error) as e:
+                call()
+            assert e.value.code == -6
+        d.set_copy_handover(False)                       # every slot on its own, still gated early
+        d.decode()
+        assert d.results().tobytes() == want.tobytes() and d.copy_count() == 0
+        assert np.array_equal(d.dump_indexes(0), idx_all)
+        d.set_llr_retention(True)
+        d.decode()
+        assert d.results().tobytes() == want.tobytes() and d.copy_handover() is False
+        assert int((d.dump_candidates(0)["is_message_present"] == 1).sum()) == len(want)
+    with hip.HipDecoder(channels=4, llr_block_channels=2, **cfg) as d:
+        with pytest.raises(hip.Msk144Error) as e:        # a blocked handle cannot retain
+            d.set_llr_retention(True)
+        assert e.value.code == -6
+        d.set_llr_retention(False)
+
+
 def test_handed_over_records_equal_their_own_decode(hip, parity_report):
     """The four 1024-channel windows bench.py cycles through, production path (64-channel blocks, copies handed over) against the same
     handle with the hand-over switched off (every slot demodulated and decoded on its own, as the reference does): lists byte-identical,
