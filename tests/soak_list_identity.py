@@ -16,6 +16,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
@@ -23,31 +24,28 @@ def main():
     ap.add_argument("--ranks", type=int, default=6, help="input sets (bench.make_inputs(rank, 1024)), four windows each")
     a = ap.parse_args()
     import bench
+    import parity
     from msk144cudecoder_amd import hipdecoder as hip
     deep = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
-    tot = dict(lists=0, records=0, copies_among_records=0, differing_lists=0, differing_records=0)
+    tot = dict(lists=0, records=0, copies_among_records=0, handed_over_slots=0, slots=0, differing_lists=0, differing_records=0)
     with hip.HipDecoder(channels=1024, max_results=1 << 20, **deep) as prod, hip.HipDecoder(channels=1024, max_results=1 << 20, llr_block_channels=1024, **deep) as full:
         for rank in range(a.ranks):
             wins, _ = bench.make_inputs(rank, 1024)
             bench._INPUTS.clear()
             for t in range(wins.shape[0]):
-                prod.submit_audio(wins[t])
-                prod.decode()
-                p = prod.results().copy()
                 full.submit_audio(wins[t])
                 full.decode()
                 f = full.results().copy()
+                prod.submit_audio(wins[t])
+                prod.decode()
+                p = prod.results().copy()
                 tot["lists"] += 1
                 tot["records"] += len(f)
-                # a record is (at least) a copy when a lower ACCEPTED slot of its (channel, group) is congruent modulo the ring (5184) or,
-                # for pattern 5 (mask 111111), modulo 864
-                key = f["channel"].astype(np.int64) * (1 << 20) + (f["item"] >> 3)
-                res = np.where(f["pattern_idx"] == 5, (f["pos"].astype(np.int64) % 5184) % 864, f["pos"].astype(np.int64) % 5184)
-                seen = {}
-                for k, r, it in zip(key, res, f["item"]):
-                    if (int(k), int(r)) in seen and seen[(int(k), int(r))] < it:
-                        tot["copies_among_records"] += 1
-                    seen.setdefault((int(k), int(r)), int(it))
+                # records whose slot was handed over: not in the production handle's index list (never demodulated or decoded itself)
+                handed = parity.handed_over_records(prod, p) if len(p) == len(f) else np.zeros(len(p), dtype=bool)
+                tot["copies_among_records"] += int(handed.sum())
+                tot["handed_over_slots"] += prod.copy_count()
+                tot["slots"] += 1024 * prod.K
                 if p.tobytes() != f.tobytes():
                     tot["differing_lists"] += 1
                     n = min(len(p), len(f))
