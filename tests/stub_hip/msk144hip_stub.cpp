@@ -10,6 +10,7 @@
 #include "../../include/msk144hip.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <future>
@@ -123,8 +124,17 @@ int msk144_frequency(const msk144_handle* h, int32_t b, float* hz)
 }
 
 int msk144_set_profiling(msk144_handle*, int32_t) { return MSK144_OK; }
-int msk144_set_llr_retention(msk144_handle*, int32_t) { return MSK144_OK; }
-int msk144_set_copy_handover(msk144_handle*, int32_t) { return MSK144_OK; }
+// MSK144_STUB_LOG_MODES=1: report on stderr what the program asks of its handles
+int msk144_set_llr_retention(msk144_handle*, int32_t retain)
+{
+    if(getenv("MSK144_STUB_LOG_MODES")) fprintf(stderr, "stub: msk144_set_llr_retention(%d)\n", retain);
+    return MSK144_OK;
+}
+int msk144_set_copy_handover(msk144_handle*, int32_t enable)
+{
+    if(getenv("MSK144_STUB_LOG_MODES")) fprintf(stderr, "stub: msk144_set_copy_handover(%d)\n", enable);
+    return MSK144_OK;
+}
 
 int msk144_stage_times(msk144_handle*, float* ms, int32_t*, int32_t)
 {

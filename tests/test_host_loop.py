@@ -74,6 +74,22 @@ def test_files_of_different_length(exe, tmp_path):
     assert m and int(m.group(1)) == max(hops) + 1 and int(m.group(2)) == sum(h + 1 for h in hops)
 
 
+def test_program_asks_for_the_batch_kernels_and_every_slot_switches_the_hand_over_off(exe, tmp_path):
+    """Every handle the program creates - its single stdin stream and the per-device handles of --inputs alike - is told that no LLR row
+    has to outlive its decode (msk144_set_llr_retention(h, 0): early gate, copies handed over); --every-slot then switches the hand-over
+    off again (msk144_set_copy_handover(h, 0))."""
+    env = dict(os.environ, MSK144_STUB_DECODE_MS="1", MSK144_STUB_LOG_MODES="1", MSK144_STUB_DEVICES="2")
+    data = marked_stream(2, 100).tobytes()
+    r = subprocess.run([exe], input=data, capture_output=True, timeout=60, env=env)
+    assert r.returncode == 0 and r.stderr.decode().count("stub: msk144_set_llr_retention(0)") == 1 and b"msk144_set_copy_handover" not in r.stderr
+    r = subprocess.run([exe, "--every-slot"], input=data, capture_output=True, timeout=60, env=env)
+    assert r.returncode == 0 and b"stub: msk144_set_llr_retention(0)" in r.stderr and r.stderr.decode().count("stub: msk144_set_copy_handover(0)") == 1
+    p = tmp_path / "s.s16"
+    p.write_bytes(data)
+    r = subprocess.run([exe, f"--inputs={p},{p},{p}", "--devices=0,1", "--every-slot"], capture_output=True, timeout=60, env=env)
+    assert r.returncode == 0 and r.stderr.decode().count("stub: msk144_set_llr_retention(0)") == 2 and r.stderr.decode().count("stub: msk144_set_copy_handover(0)") == 2
+
+
 def test_inputs_file_and_stdin_single_stream(exe, tmp_path):
     x = marked_stream(3, 7)
     r = subprocess.run([exe], input=x.tobytes(), capture_output=True, timeout=60)
