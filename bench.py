@@ -700,9 +700,9 @@ def run_worker(args) -> int:
                        "backend": Backend.name, "launch": "torch.distributed.run" if distributed else "single process",
                        "real_time_channels": value / be.K / (12000.0 / 2592.0),
                        "real_time_channels_note": "hot-clock GPU-only arithmetic (windows/s / 4.63 at the back-to-back clock of ~2.35 GHz).  The stream decoder program itself, "
-                                                  "measured over 60 s of signal per stream (tools/host_scale.py, profiles/r05_host_scale_*_60s_final.json): with every stream's hop "
-                                                  "falling due together 4096 real-time streams - 0 late of 1.14 M hops, worst hop latency 171 ms of the 210 ms limit - and 4608 at the "
-                                                  "edge (0 late, 193 ms); with every stream on its own hop phase 5376 / 5888 streams - 0 late, worst 52 / 66 ms.  A GPU that idles "
+                                                  "measured over 60 s of signal per stream (tools/host_scale.py, profiles/r06_host_scale_*_60s.json): with every stream's hop "
+                                                  "falling due together 4096 real-time streams - 0 late of 1.14 M hops, worst hop latency 170 ms of the 210 ms limit - and 4608 at the "
+                                                  "edge (0 late, 190 ms); with every stream on its own hop phase 5376 / 5888 streams - 0 late, worst 53 / 69 ms.  A GPU that idles "
                                                   "between hops starts each batch at 1.8-2.0 GHz (profiles/r04_idle_gap.json), so a lightly loaded program runs its kernels ~8 % slower "
                                                   "than this line"},
             "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
