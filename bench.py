@@ -445,6 +445,9 @@ def parse_args(argv=None):
                     help="skip the short legs appended after the timed region: value_every_slot_decoded (the same step with the copy hand-over off; every rank "
                          "runs it) and, single-GPU runs only, value_incl_h2d (pinned host windows), frontend_method1 (FFT front end beside the FIR one) and "
                          "configs4_iq (BASELINE configs[4])")
+    ap.add_argument("--every-slot", action="store_true",
+                    help="run the TIMED region with the copy hand-over off (msk144_set_copy_handover(h, 0)): `value` is then slots fully evaluated per second, as the "
+                         "reference computes them; the value_every_slot_decoded leg is dropped (it would repeat the timed region)")
     ap.add_argument("--launcher", action="store_true", help="go through the N-rank launcher even for --gpus 1 (exercises the RCCL gather path)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend-module", default=None, help="TEST HOOK: module providing Backend (e.g. tests/stub_backend.py on gloo); the line is then labelled as such")
@@ -541,6 +544,8 @@ def run_worker(args) -> int:
     channel_base, _ = sharding.shard_channels(channels * world, rank, world)   # rank r owns global channels [r*C, (r+1)*C)
     be = Backend(rank, local_rank, channels, channel_base, args.llr_block)
     cand_per_step = be.cand_per_step
+    if args.every_slot and Backend is HipBackend:
+        be.dec.set_copy_handover(False)
 
     gather = None
     if distributed:

@@ -58,3 +58,10 @@ def test_distributed_line_carries_the_cpu_baseline():
     assert abs(su["drift_last_vs_first"]) < 0.05
     assert all(1200.0 < su["clock_mhz"][k] < 2700.0 for k in ("first", "mid", "last")), su["clock_mhz"]
     assert dist["gather"]["records_last_step"] == dist["decodes_last_step"]
+
+
+def test_every_slot_flag_times_the_region_with_the_hand_over_off():
+    line = _bench(["--every-slot", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extra-legs"])
+    assert line["copy_handover"] == {"enabled": False, "slots_handed_over_last_step": 0, "share_of_slots": 0.0}
+    assert line["config"]["copies_computed_once"] is False and "fully evaluated" in line["config"]["value_counts"]
+    assert "value_every_slot_decoded" not in line and "computed again, as in the reference" in line["roofline"]["mode"]
