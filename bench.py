@@ -133,7 +133,7 @@ class HipBackend:
         self.wins_dev = torch.from_numpy(self.wins_host).cuda(local_rank)   # inputs resident in HBM before timing
         self.dec = HipDecoder(center=1500.0, width=WIDTH, step=STEP, depth=DEPTH, nbadsync_threshold=NBADSYNC, read_mode=1,
                               analytic_method=2, channels=channels, device=local_rank, max_results=1 << 20, llr_block_channels=llr_block)
-        self.llr_block = self.dec.params.llr_block_channels or min(channels, 64)
+        self.llr_block = self.dec.llr_block
         assert self.stream.cuda_stream != 0
         self.dec.set_stream(self.stream.cuda_stream)
         self.dec.set_channel_base(channel_base)
@@ -423,7 +423,7 @@ def configs4_leg(be, n_steps: int = 3, channels: int = 4096):
         return {"workload": f"BASELINE configs[4]: {channels} int8 I/Q channels (--read-mode=2, centre 0 Hz), width=500 step=1 depth=6 nbadsync-threshold=3 "
                             f"(F={d.F}, {d.K} candidates/window), one window per channel per step",
                 "value": channels * d.K * n_steps / el, "unit": "candidates/s", "steps": n_steps, "warmup": 1, "ms_per_step": el / n_steps * 1e3,
-                "stage_ms": {n: round(st[n][0], 4) for n in be.T_NAMES}, "llr_block_channels": d.params.llr_block_channels or 64,
+                "stage_ms": {n: round(st[n][0], 4) for n in be.T_NAMES}, "llr_block_channels": d.llr_block,
                 "decodes_last_step": int(len(res)), "pinged_channels": len(truth), "pinged_channels_decoded": len(hit)}
 
 
@@ -651,7 +651,8 @@ def run_worker(args) -> int:
         if os.path.exists(COUNTERS_FILE) and channels == CHANNELS_PER_GPU and Backend is HipBackend:
             try:
                 cj = json.load(open(COUNTERS_FILE))
-                if cj.get("kernel_source_sha") == kernel_source_sha():
+                shape_ok = abs(cj.get("kernels", {}).get(dom + "_kernel", {}).get("launches_per_step", launches) - launches) < 0.5    # per-launch figures: same block size
+                if cj.get("kernel_source_sha") == kernel_source_sha() and shape_ok:
                     static = f"profiles/counters.json@{cj.get('commit', '?')} (kernel_source_sha {cj['kernel_source_sha']})"
                     traffic = cj.get("kernels", {}).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
                     valu = {"unit": "wave-instr/s", "peak": VALU_PEAK_WAVE_INSTR,
@@ -670,7 +671,7 @@ def run_worker(args) -> int:
                             lds[k + "_kernel"] = {"frac": n_lds / (256 * 2.4e9 * stage[k][0] * 1e-3),
                                                   "conflict_share": cj["kernels"][k + "_kernel"].get("SQ_LDS_BANK_CONFLICT", 0.0) / n_lds}
                 else:
-                    static = "profiles/counters.json is stale for these kernel sources: traffic/valu_issue omitted"
+                    static = "profiles/counters.json is stale for these kernel sources or this block size: traffic/valu_issue omitted"
             except Exception as e:  # noqa: BLE001
                 static = f"profiles/counters.json unreadable: {e}"
         if llr_block >= channels:

@@ -105,9 +105,9 @@ typedef struct msk144_params
     int32_t llr_block_channels; /* channels per softbits->index->LDPC block (reference: result_keeper.cuh:105-115 keeps every
                                    candidate's 128 softbits; ldpc_kernel.cuh:116-142 reads them back).  The LLR rows of a block
                                    (block x items x 512 B) are produced and consumed back to back, so the LLR store never grows
-                                   with the batch (0.79 GB per 64-channel block at the deep config instead of 12.6 GB per 1024
-                                   channels).  0 = automatic: min(channels, 64), the fastest setting measured (16: +5 %, 32: +1.5 %,
-                                   128: +1.5 %, 1024: +3 % step time).  With fewer channels per block than channels no row outlives
+                                   with the batch (1.58 GB per 128-channel block at the deep config instead of 12.6 GB per 1024
+                                   channels).  0 = automatic: min(channels, 128), the bottom of a flat valley on the 1024-channel bench
+                                   step (48: +1.4 %, 64: +0.8 %, 96: +0.3 %, 160: +0.1 %, 192: +0.3 %, 256: +0.9 % step time).  With fewer channels per block than channels no row outlives
                                    its block, and a candidate the nbadsync gate drops (index_kernel.cuh:7-76) is not demodulated
                                    beyond its sync check.  Candidate dumps need every row retained:
                                    = channels: retain everything, every candidate in full (parity-dump mode) */
@@ -206,7 +206,7 @@ int msk144_set_channel_base(msk144_handle* h, int32_t base);
  *                                   (such a handle always computes every slot: its dumps show each slot's own row).
  * Takes effect at the next decode.  msk144_copy_count: slots of the last decode that were handed over (0 when switched off). */
 int msk144_set_copy_handover(msk144_handle* h, int32_t enable);
-/* A handle whose one block covers all its channels (llr_block_channels = channels; the default up to 64 channels, e.g. the single
+/* A handle whose one block covers all its channels (llr_block_channels = channels; the default up to 128 channels, e.g. the single
  * stream of the reference's program) keeps every candidate's 128 softbits readable after the decode, as the reference's ResultItem
  * array does (result_keeper.cuh:17-32): msk144_dump_candidates, partial stage runs and msk144_load_candidates work, and every slot is
  * demodulated in full.  A caller that only reads the result list - the stream program - says so with

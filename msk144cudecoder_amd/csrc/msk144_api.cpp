@@ -102,6 +102,10 @@ namespace
 
 thread_local std::string g_create_error;
 
+// Channels per softbits -> index -> LDPC block when the caller leaves msk144_params.llr_block_channels at 0 (include/msk144hip.h): the
+// bottom of a flat valley on the 1024-channel bench step (profiles/r06_sweep_ldpc_grid_and_block.txt, r06_sweep_block.txt)
+constexpr int kDefaultLlrBlockChannels = 128;
+
 int fail(msk144_handle* h, int code, const std::string& msg)
 {
     if(h) h->error = msg;
@@ -366,7 +370,7 @@ int msk144_create(const msk144_params* params, msk144_handle** out)
     if(!h) return fail(nullptr, MSK144_ENOMEM, "out of host memory");
     h->params = *params;
     h->params.scan_depth = clamp_scan_depth(params->scan_depth);
-    h->llr_block = params->llr_block_channels > 0 ? params->llr_block_channels : (params->channels <= 64 ? params->channels : 64);
+    h->llr_block = params->llr_block_channels > 0 ? params->llr_block_channels : (params->channels <= kDefaultLlrBlockChannels ? params->channels : kDefaultLlrBlockChannels);
     if(h->llr_block > params->channels) h->llr_block = params->channels;
     h->params.llr_block_channels = h->llr_block;
     for(int s = 0; s < MSK144_T_COUNT; s++) h->last_call[s] = -1;

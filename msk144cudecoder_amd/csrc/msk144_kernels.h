@@ -31,7 +31,7 @@ struct DeviceStore
     int32_t max_results;
     int32_t channel_base;     // added to the channel number in result records (multi-GPU sharding)
     // Blocked staging: softbits / index / LDPC are launched per block of channels [ch0, ch0 + nch), so the LLR store is
-    // llr_block x K x 512 B however large the batch is (a 64-channel block: 0.79 GB at the deep config; the reference keeps
+    // llr_block x K x 512 B however large the batch is (a 128-channel block: 1.58 GB at the deep config; the reference keeps
     // 512 B of softbits in every 632-byte item).  llr is indexed by (channel - ch0), every other array by the absolute
     // channel.  scan, front ends and collect always cover all `channels`.
     int32_t ch0;

@@ -18,6 +18,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmsk144hip.so")
 
 STAGE_SCAN, STAGE_SOFTBITS, STAGE_INDEX, STAGE_LDPC, STAGE_COLLECT, STAGE_ALL = 1, 2, 4, 8, 16, 31
+DEFAULT_LLR_BLOCK_CHANNELS = 128   # msk144_api.cpp kDefaultLlrBlockChannels: channels per block when llr_block_channels = 0
 T_NAMES = ("frontend", "scan", "softbits", "index", "ldpc", "collect", "h2d", "d2h")
 
 # every symbol include/msk144hip.h declares (tests check the library exports each of them)
@@ -148,6 +149,7 @@ class HipDecoder:
         self.F, self.D, self.K = f.value, d.value, k.value
         self.channels = channels
         self.read_mode = read_mode
+        self.llr_block = min(channels, llr_block_channels) if llr_block_channels > 0 else min(channels, DEFAULT_LLR_BLOCK_CHANNELS)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

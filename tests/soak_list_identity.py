@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off soak: the production result list (64-channel blocks, gated softbits, periodic copies handed to the lower slot of their
+"""One-off soak: the production result list (default 128-channel blocks, gated softbits, periodic copies handed to the lower slot of their
 group) against the retain-everything list (every candidate demodulated and decoded on its own, as the reference does) on many
 1024-channel bench windows - byte for byte.  A handed-over copy reports its lower slot's nbadsync / iterations / hard errors /
 payload; computed on its own (other float association of the same frame sums) those could differ only in a marginal case, which

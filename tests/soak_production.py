@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off soak of the PRODUCTION path (default 64-channel blocks, gated softbits - what bench.py times) against the oracle at
+"""One-off soak of the PRODUCTION path (default 128-channel blocks, gated softbits - what bench.py times) against the oracle at
 BASELINE configs[2] size: for every staged window of the bench inputs, the 1024-channel batch is decoded once, and N sampled channels are
 compared with the oracle exactly as tests/test_gpu_full.py does (tests/parity.py: records == accepted candidates of the channel's
 dump, dump vs decode_window stage by stage with verified near-ties only).  TEST INFRASTRUCTURE: uses oracle/ and tests/parity.py.

@@ -30,7 +30,7 @@ def test_launcher_line_matches_the_plain_run():
     assert g["peak_records_per_rank"][0] <= g["capacity_per_rank"] and g["ms_per_step"] is not None
     assert abs(dist["value"] / plain["value"] - 1.0) < 0.05, (dist["value"], plain["value"])
     for line in (plain, dist):
-        assert line["config"]["softbits_gate_early"] is True and line["config"]["llr_store"] == "blocked/64"
+        assert line["config"]["softbits_gate_early"] is True and line["config"]["llr_store"] == "blocked/128"
         assert line["roofline"]["kernel"] == "ldpc_kernel" and 0.0 < line["roofline"]["frac"] < 1.0
         assert line["rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])
         # `value` counts reported slots; the line says how many were handed over and carries the every-slot figure beside it

@@ -58,7 +58,7 @@ def test_1024_channel_batch_properties(orc, hip, parity_report):
         d.decode()
         res2 = d.results().copy()
     assert res1.tobytes() == res2.tobytes()                             # deterministic
-    # the PRODUCTION path - default blocked staging (64-channel blocks, softbits_kernel<true>: gated-out candidates stop after
+    # the PRODUCTION path - default blocked staging (128-channel blocks, softbits_kernel<true, true>: gated-out candidates stop after
     # their sync check), what bench.py times - must give the retained-mode list byte for byte at full size
     with hip.HipDecoder(channels=1024, max_results=1 << 20, **DEEP) as dp:
         dp.submit_audio(wins[2])
@@ -90,7 +90,7 @@ def test_1024_channel_batch_properties(orc, hip, parity_report):
             d1.submit_audio(wins[2, ch])
             d1.decode()
             assert d1.dump_candidates(0).tobytes() == blob              # batch == single, bit for bit
-    # production list against the oracle DIRECTLY: 16 sampled channels spread over the 64-channel blocks, eight with a decoded
+    # production list against the oracle DIRECTLY: 16 sampled channels spread over the 128-channel blocks, eight with a decoded
     # ping and eight noise-only - the records are the accepted candidates of the channel's dump, and the dump agrees with the oracle
     with_ping = sorted(decoded_channels & pinged)
     noise = [c for c in range(1024) if c not in pinged]
@@ -156,7 +156,7 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
         d.decode()
         res2 = d.results().copy()
     assert res1.tobytes() == res2.tobytes()                             # deterministic
-    # production path (default 64-channel blocks, gated softbits) at full size: same list, byte for byte
+    # production path (default 128-channel blocks, gated softbits, copies handed over) at full size: same list, byte for byte
     with hip.HipDecoder(read_mode=2, channels=nch, max_results=1 << 20, **cfg) as dp:
         dp.submit_iq(wins)
         dp.decode()
@@ -223,7 +223,7 @@ def test_blocked_staging_equals_retained(hip):
         d.submit_audio(wins[1])
         d.decode()
         want = d.results().copy()
-    for blk in (0, 16, 7, 64):          # 0 = automatic (64 for more than 64 channels); 7: last block is short
+    for blk in (0, 16, 7, 64):          # 0 = automatic (128 for more than 128 channels: 128 + 72 here); 7: last block is short
         with hip.HipDecoder(channels=200, max_results=1 << 20, llr_block_channels=blk, **DEEP) as d:
             d.submit_audio(wins[1])
             d.decode()
@@ -349,7 +349,7 @@ def test_single_stream_handle_without_llr_retention(hip):
 
 
 def test_handed_over_records_equal_their_own_decode(hip, parity_report):
-    """The four 1024-channel windows bench.py cycles through, production path (64-channel blocks, copies handed over) against the same
+    """The four 1024-channel windows bench.py cycles through, production path (128-channel blocks, copies handed over) against the same
     handle with the hand-over switched off (every slot demodulated and decoded on its own, as the reference does): lists byte-identical,
     and the records whose slot was handed over - never computed themselves - are counted and compared on their own."""
     import bench

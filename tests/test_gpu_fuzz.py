@@ -69,8 +69,10 @@ def test_random_configuration(orc, hip, parity_report, seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MSK144_FUZZ_SEEDS", "12"))))
 def test_random_configuration_blocked_staging(hip, seed):
     """The same random configurations on three channels, once with every LLR row retained (every candidate demodulated in full) and
-    once in blocked staging with one channel per block (softbits stops at the sync check for candidates the gate drops): the
-    result lists must be identical byte for byte, for every threshold 0..5 and depth 1..8 the sweep draws."""
+    once in blocked staging with one channel per block (softbits stops at the sync check for candidates the gate drops, copies are
+    handed over), plus the two modes in between - the one-block handle after msk144_set_llr_retention(h, 0) and the blocked handle
+    after msk144_set_copy_handover(h, 0): the result lists must be identical byte for byte, for every threshold 0..5 and depth 1..8
+    the sweep draws."""
     cfg, read_mode, method, x, _ = _case(seed)
     rng = np.random.default_rng(5000 + seed)
     if read_mode == 1:
@@ -83,4 +85,12 @@ def test_random_configuration_blocked_staging(hip, seed):
             (d.submit_audio if read_mode == 1 else d.submit_iq)(batch)
             d.decode()
             got.append(d.results().copy().tobytes())
-    assert got[0] == got[1]
+            if blk == 1:
+                d.set_copy_handover(False)           # blocked staging with every slot computed on its own
+                d.decode()
+                got.append(d.results().copy().tobytes())
+            else:
+                d.set_llr_retention(False)           # the one-block handle told not to retain (what msk144hipdecoder asks): batch kernels, copies handed over
+                d.decode()
+                got.append(d.results().copy().tobytes())
+    assert got[0] == got[1] == got[2] == got[3]

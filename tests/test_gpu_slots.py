@@ -163,9 +163,9 @@ def test_slot_state_errors(hip):
 def test_partial_hop_covers_only_its_streams(hip):
     """msk144_submit_slot_n: a hop over the first n windows of the slot gives exactly the records of an n-channel handle (every
     kernel, copy and result sized for n), whatever the handle's capacity and whatever a previous, larger hop left behind."""
-    capacity = 100                                   # > 64: blocked staging with gated softbits, two blocks for n = 70
+    capacity = 100                                   # 64-channel blocks: blocked staging with gated softbits, two blocks for n = 70
     wins = _windows(1, capacity, 21)[0]
-    with hip.HipDecoder(channels=capacity, max_results=1 << 16, **CFG) as d:
+    with hip.HipDecoder(channels=capacity, max_results=1 << 16, llr_block_channels=64, **CFG) as d:
         d.input_slot(0)[:] = wins
         d.submit_slot(0)
         d.decode()

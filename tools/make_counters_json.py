@@ -62,7 +62,7 @@ def main():
     out = {
         "_how": "tools/collect_profiles.sh on one MI355X: separate rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (1024 channels, width 500 / "
                 "step 1 / depth 6 / threshold 3); values are per bench STEP (per-launch average x launches per step; blocked staging launches softbits/index/ldpc once per "
-                "64-channel block).  hbm_bytes_per_step = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the kernel's launches of one step; hbm_bytes_per_launch = that / launches_per_step.",
+                "channel block: 128 channels by default).  hbm_bytes_per_step = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the kernel's launches of one step; hbm_bytes_per_launch = that / launches_per_step.",
         "kernel_source_sha": bench.kernel_source_sha(),
         "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
         "candidates_per_step": cand,
