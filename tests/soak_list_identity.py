@@ -19,10 +19,47 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def iq_soak(n_seeds):
+    """The LDPC-iteration-heavy stress workload (pings at -6..-2 dB: marginal softbits and BP decisions are likelier than in the audio bench
+    windows): hand-over on against hand-over off on one blocked handle."""
+    import parity
+    from msk144cudecoder_amd import hipdecoder as hip
+    from msk144cudecoder_amd import synth
+    cfg = dict(center=0.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
+    tot = dict(workload="configs[4]: 4096 int8 IQ channels per list", lists=0, records=0, copies_among_records=0, handed_over_slots=0, slots=0, differing_lists=0, differing_records=0)
+    with hip.HipDecoder(read_mode=2, channels=4096, max_results=1 << 20, **cfg) as d:
+        for seed in range(100, 100 + n_seeds):
+            wins, _ = synth.iq_low_snr_batch(4096, seed)
+            d.set_copy_handover(True)
+            d.submit_iq(wins)
+            d.decode()
+            p = d.results().copy()
+            handed = parity.handed_over_records(d, p)
+            tot["handed_over_slots"] += d.copy_count()
+            d.set_copy_handover(False)
+            d.decode()
+            f = d.results().copy()
+            tot["lists"] += 1
+            tot["records"] += len(f)
+            tot["slots"] += 4096 * d.K
+            tot["copies_among_records"] += int(handed.sum())
+            if p.tobytes() != f.tobytes():
+                tot["differing_lists"] += 1
+                n = min(len(p), len(f))
+                tot["differing_records"] += int(np.count_nonzero(p[:n] != f[:n])) + abs(len(p) - len(f))
+            print(f"seed {seed}: {tot}", file=sys.stderr, flush=True)
+    print(json.dumps(tot), flush=True)
+    return 0 if tot["differing_lists"] == 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, default=6, help="input sets (bench.make_inputs(rank, 1024)), four windows each")
+    ap.add_argument("--iq-seeds", type=int, default=0, help="instead: this many BASELINE configs[4] batches (4096 low-SNR IQ channels, synth.iq_low_snr_batch(4096, seed)), "
+                                                              "production list against the SAME handle with the hand-over switched off (every slot computed on its own)")
     a = ap.parse_args()
+    if a.iq_seeds > 0:
+        return iq_soak(a.iq_seeds)
     import bench
     import parity
     from msk144cudecoder_amd import hipdecoder as hip

@@ -89,6 +89,22 @@ def compare_pairs(items, copies, lowers, threshold):
     return out
 
 
+def draw_marginal_window(rng, i):
+    """--mode marginal: every window carries ONE ping that fills the window (6 frames from a start inside the first frame, so that the
+    six-frame mask 111111 - the pattern whose slots are mostly periodic copies - is the one that decodes it) at an SNR around the
+    threshold of the averaged decode (-10 .. -4 dB per frame): accepted copies with marginal softbits and BP runs that need many
+    iterations are as likely as this workload family can make them."""
+    from msk144cudecoder_amd import synth
+    kind = "audio" if i % 2 == 0 else "iq"
+    width = float((40.0, 80.0)[int(rng.integers(0, 2))])
+    center = 1500.0 if kind == "audio" else 0.0
+    cfg = dict(center=center, width=width, step=1.0, depth=6 if i % 4 < 3 else 8, nbadsync_threshold=int(rng.integers(3, 6)))
+    ping = synth.Ping(synth.random_message(rng), int(rng.integers(0, 864)), 6, center + float(rng.uniform(-0.4, 0.4)) * width, float(rng.uniform(-10.0, -4.0)),
+                      float(rng.uniform(0, 6.28)))
+    raw = synth.synth_audio(5184, [ping], 1000.0, rng) if kind == "audio" else synth.synth_iq(5184, [ping], 20.0, rng)
+    return kind, cfg, raw, 1
+
+
 def draw_window(rng, i):
     """(kind, oracle config, analytic-signal maker) of window i: the workload mix of the module docstring."""
     from msk144cudecoder_amd import synth
@@ -112,7 +128,7 @@ def draw_window(rng, i):
     return kind, cfg, raw, len(pings)
 
 
-def run(windows: int, threads: int, seed: int, progress=None):
+def run(windows: int, threads: int, seed: int, progress=None, mode: str = "mix"):
     from oracle import oracle as orc
     orc.build()
     rng = np.random.default_rng(770000 + seed)
@@ -123,7 +139,7 @@ def run(windows: int, threads: int, seed: int, progress=None):
     t0 = time.perf_counter()
     oracles = {}
     for i in range(windows):
-        kind, cfg, raw, n_pings = draw_window(rng, i)
+        kind, cfg, raw, n_pings = (draw_marginal_window if mode == "marginal" else draw_window)(rng, i)
         key = tuple(sorted(cfg.items()))
         if key not in oracles:
             oracles[key] = orc.Oracle(threads=threads, **cfg)
@@ -142,7 +158,7 @@ def run(windows: int, threads: int, seed: int, progress=None):
         m["with_ping"] += int(n_pings > 0)
         if progress and (i + 1) % progress == 0:
             print(f"{i + 1}/{windows} windows, {time.perf_counter() - t0:.0f} s: periodic {tot['periodic_copies']}", file=sys.stderr, flush=True)
-    out = {"windows": windows, "seed": seed, "slots": slots, "seconds": round(time.perf_counter() - t0, 1), "mix": mix, **tot}
+    out = {"windows": windows, "seed": seed, "mode": mode, "slots": slots, "seconds": round(time.perf_counter() - t0, 1), "mix": mix, **tot}
     for name in ("ring_wrap_twins", "periodic_copies"):
         t = tot[name]
         n = t["pairs"]
@@ -160,8 +176,9 @@ def main():
     ap.add_argument("--windows", type=int, default=2000)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--mode", choices=("mix", "marginal"), default="mix", help="mix: the workload mix of the docstring; marginal: window-filling pings around the decode threshold")
     a = ap.parse_args()
-    print(json.dumps(run(a.windows, a.threads, a.seed, progress=100)), flush=True)
+    print(json.dumps(run(a.windows, a.threads, a.seed, progress=100, mode=a.mode)), flush=True)
     return 0
 
 
