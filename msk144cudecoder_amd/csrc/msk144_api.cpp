@@ -40,6 +40,7 @@ struct msk144_handle
 
     int llr_block = 1;  // channels per softbits->index->LDPC block
     bool retained = true;  // every LLR row of a decode stays readable (one block covers all channels and msk144_set_llr_retention was not switched off)
+    bool rows_valid = true;  // the LLR store holds every row of the last softbits run (false after a decode without retention, until the next retained one)
     int active = 1;     // channels the current hop covers (msk144_submit_slot_n: the first n of the slot); <= st.channels
     bool have_window = false;
     bool decoded = false;
@@ -644,6 +645,7 @@ int msk144_decode_stages(msk144_handle* h, uint32_t stages)
         ev_end(h, MSK144_T_SCAN);
     }
     // softbits -> index -> LDPC, one channel block at a time (one block = everything unless llr_block_channels says otherwise)
+    if(stages & MSK144_STAGE_SOFTBITS) h->rows_valid = h->retained;
     if(stages & mid)
     {
         DeviceStore blk = cur;
@@ -927,6 +929,7 @@ int msk144_dump_candidates(msk144_handle* h, int32_t channel, msk144_candidate* 
 {
     if(!h || !out || channel < 0 || channel >= h->st.channels) return fail(h, MSK144_EINVAL, "bad argument");
     if(!h->retained) return fail(h, MSK144_ENOTRETAINED, "LLR rows are not retained (blocked staging, or msk144_set_llr_retention(h, 0)); create the handle with llr_block_channels = channels for candidate dumps");
+    if(!h->rows_valid) return fail(h, MSK144_ENOTRETAINED, "the last decode ran without LLR retention: its rows are incomplete; decode again now that retention is on");
     int rc = msk144_synchronize(h);
     if(rc != MSK144_OK) return rc;
     const DeviceStore& st = h->st;

@@ -338,6 +338,9 @@ def test_single_stream_handle_without_llr_retention(hip):
         assert d.results().tobytes() == want.tobytes() and d.copy_count() == 0
         assert np.array_equal(d.dump_indexes(0), idx_all)
         d.set_llr_retention(True)
+        with pytest.raises(hip.Msk144Error) as e:        # retention is back on, but the rows in the store are those of a decode without it
+            d.dump_candidates(0)
+        assert e.value.code == -6
         d.decode()
         assert d.results().tobytes() == want.tobytes() and d.copy_handover() is False
         assert int((d.dump_candidates(0)["is_message_present"] == 1).sum()) == len(want)
