@@ -217,6 +217,8 @@ int msk144_set_copy_handover(msk144_handle* h, int32_t enable);
  *                                   channels.
  * Takes effect at the next decode. */
 int msk144_set_llr_retention(msk144_handle* h, int32_t retain);
+/* channels per softbits -> index -> LDPC block this handle decodes in (msk144_params.llr_block_channels after the automatic choice) */
+int msk144_llr_block_channels(const msk144_handle* h, int32_t* channels_per_block);
 int msk144_copy_handover(const msk144_handle* h, int32_t* enabled);
 int msk144_copy_count(msk144_handle* h, int64_t* slots);
 

@@ -752,6 +752,13 @@ int msk144_set_llr_retention(msk144_handle* h, int32_t retain)
     return MSK144_OK;
 }
 
+int msk144_llr_block_channels(const msk144_handle* h, int32_t* channels_per_block)
+{
+    if(!h || !channels_per_block) return MSK144_EINVAL;
+    *channels_per_block = h->llr_block;
+    return MSK144_OK;
+}
+
 int msk144_set_copy_handover(msk144_handle* h, int32_t enable)
 {
     if(!h) return MSK144_EINVAL;

@@ -18,7 +18,6 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmsk144hip.so")
 
 STAGE_SCAN, STAGE_SOFTBITS, STAGE_INDEX, STAGE_LDPC, STAGE_COLLECT, STAGE_ALL = 1, 2, 4, 8, 16, 31
-DEFAULT_LLR_BLOCK_CHANNELS = 128   # msk144_api.cpp kDefaultLlrBlockChannels: channels per block when llr_block_channels = 0
 T_NAMES = ("frontend", "scan", "softbits", "index", "ldpc", "collect", "h2d", "d2h")
 
 # every symbol include/msk144hip.h declares (tests check the library exports each of them)
@@ -30,7 +29,7 @@ ABI_SYMBOLS = (
     "msk144_dump_indexes", "msk144_load_candidates", "msk144_set_profiling", "msk144_stage_times",
     "msk144_input_slot", "msk144_submit_slot", "msk144_submit_slot_n", "msk144_fetch_async", "msk144_fetch_wait", "msk144_hop_slot", "msk144_push_hops",
     "msk144_device_count", "msk144_clock_probe", "msk144_set_copy_handover", "msk144_copy_handover", "msk144_copy_count",
-    "msk144_set_llr_retention",
+    "msk144_set_llr_retention", "msk144_llr_block_channels",
 )
 
 
@@ -115,6 +114,7 @@ def load_library(path: Optional[str] = None):
     L.msk144_clock_probe.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.msk144_set_copy_handover.argtypes = [vp, i32]
     L.msk144_set_llr_retention.argtypes = [vp, i32]
+    L.msk144_llr_block_channels.argtypes = [vp, C.POINTER(i32)]
     L.msk144_copy_handover.argtypes = [vp, C.POINTER(i32)]
     L.msk144_copy_count.argtypes = [vp, C.POINTER(C.c_int64)]
     if path is None:
@@ -149,7 +149,9 @@ class HipDecoder:
         self.F, self.D, self.K = f.value, d.value, k.value
         self.channels = channels
         self.read_mode = read_mode
-        self.llr_block = min(channels, llr_block_channels) if llr_block_channels > 0 else min(channels, DEFAULT_LLR_BLOCK_CHANNELS)
+        b = C.c_int32()
+        self._chk(self.L.msk144_llr_block_channels(self.h, C.byref(b)))
+        self.llr_block = b.value            # channels per softbits -> index -> LDPC block (the library's choice when llr_block_channels = 0)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

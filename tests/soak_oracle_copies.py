@@ -128,9 +128,10 @@ def draw_window(rng, i):
     return kind, cfg, raw, len(pings)
 
 
-def run(windows: int, threads: int, seed: int, progress=None, mode: str = "mix"):
+def run(windows: int, threads: int, seed: int, progress=None, mode: str = "mix", variant: str = ""):
     from oracle import oracle as orc
     orc.build()
+    library = orc.fma_lib(variant) if variant else None     # one of the builds that bracket the reference's own FMA contraction / math library (oracle/Makefile `fma`)
     rng = np.random.default_rng(770000 + seed)
     tot = {"ring_wrap_twins": dict.fromkeys(COUNT_KEYS, 0), "periodic_copies": dict.fromkeys(COUNT_KEYS, 0)}
     tot["ring_wrap_twins"]["llr_max_rel"] = tot["periodic_copies"]["llr_max_rel"] = 0.0
@@ -142,7 +143,7 @@ def run(windows: int, threads: int, seed: int, progress=None, mode: str = "mix")
         kind, cfg, raw, n_pings = (draw_marginal_window if mode == "marginal" else draw_window)(rng, i)
         key = tuple(sorted(cfg.items()))
         if key not in oracles:
-            oracles[key] = orc.Oracle(threads=threads, **cfg)
+            oracles[key] = orc.Oracle(threads=threads, library=library, **cfg)
         o = oracles[key]
         cd = o.frontend_audio(raw, 2) if kind == "audio" else o.frontend_iq(raw)
         items, _ = o.decode_window(cd)
@@ -158,7 +159,7 @@ def run(windows: int, threads: int, seed: int, progress=None, mode: str = "mix")
         m["with_ping"] += int(n_pings > 0)
         if progress and (i + 1) % progress == 0:
             print(f"{i + 1}/{windows} windows, {time.perf_counter() - t0:.0f} s: periodic {tot['periodic_copies']}", file=sys.stderr, flush=True)
-    out = {"windows": windows, "seed": seed, "mode": mode, "slots": slots, "seconds": round(time.perf_counter() - t0, 1), "mix": mix, **tot}
+    out = {"windows": windows, "seed": seed, "mode": mode, "oracle_build": variant or "parity (-ffp-contract=off)", "slots": slots, "seconds": round(time.perf_counter() - t0, 1), "mix": mix, **tot}
     for name in ("ring_wrap_twins", "periodic_copies"):
         t = tot[name]
         n = t["pairs"]
@@ -177,8 +178,10 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", choices=("mix", "marginal"), default="mix", help="mix: the workload mix of the docstring; marginal: window-filling pings around the decode threshold")
+    ap.add_argument("--variant", default="", choices=("", "contract-fast", "forced-fma", "cuda-libm", "cuda-like"),
+                    help="run on one of the oracle builds that bracket the reference's FMA contraction and math library instead of the parity build")
     a = ap.parse_args()
-    print(json.dumps(run(a.windows, a.threads, a.seed, progress=100, mode=a.mode)), flush=True)
+    print(json.dumps(run(a.windows, a.threads, a.seed, progress=100, mode=a.mode, variant=a.variant)), flush=True)
     return 0
 
 

@@ -124,6 +124,12 @@ int msk144_frequency(const msk144_handle* h, int32_t b, float* hz)
 }
 
 int msk144_set_profiling(msk144_handle*, int32_t) { return MSK144_OK; }
+int msk144_llr_block_channels(const msk144_handle* h, int32_t* n)
+{
+    if(!h || !n) return MSK144_EINVAL;
+    *n = h->p.channels;
+    return MSK144_OK;
+}
 // MSK144_STUB_LOG_MODES=1: report on stderr what the program asks of its handles
 int msk144_set_llr_retention(msk144_handle*, int32_t retain)
 {

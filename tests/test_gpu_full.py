@@ -225,6 +225,7 @@ def test_blocked_staging_equals_retained(hip):
         want = d.results().copy()
     for blk in (0, 16, 7, 64):          # 0 = automatic (128 for more than 128 channels: 128 + 72 here); 7: last block is short
         with hip.HipDecoder(channels=200, max_results=1 << 20, llr_block_channels=blk, **DEEP) as d:
+            assert d.llr_block == (blk or 128)      # msk144_llr_block_channels: the library's automatic choice is 128 channels per block
             d.submit_audio(wins[1])
             d.decode()
             got = d.results().copy()
