@@ -24,6 +24,8 @@
  *   msk144_destroy           ~MSK144SearchContext / deinit        msk_context.cuh:81-120
  *   msk144_device_count      cudaGetDeviceCount behind cudaSetDeviceFlags (the reference drives device 0 only; the multi-device
  *                            stream program asks how many it may split its streams over)   main.cu:115
+ *   msk144_llr_block_channels how many channels' softbits the handle keeps at a time (the reference keeps 512 B in every ResultItem of its one
+ *                            stream, result_keeper.cuh:17-32; here a block of channels shares one LLR store)
  *   msk144_set_llr_retention whether the 128 softbits of every candidate stay readable after the decode, as in the reference's
  *                            ResultItem array (result_keeper.cuh:17-32, 105-115) - the stream program never reads them
  *   msk144_set_copy_handover whether slots that fold the same frames as a lower slot of their group are computed again, as
