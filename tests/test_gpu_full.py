@@ -164,7 +164,7 @@ def test_config4_iq_4096_low_snr_channels(orc, hip, parity_report):
         handed = parity.handed_over_records(dp, prod)
         handed_slots = dp.copy_count()
     assert prod.tobytes() == res1.tobytes()
-    assert handed.sum() > 1000 and prod[handed].tobytes() == res1[handed].tobytes()      # slots never computed themselves = their own decode
+    assert handed.sum() > 5000 and prod[handed].tobytes() == res1[handed].tobytes()      # slots never computed themselves = their own decode (6541 on this workload)
     key = res1["channel"].astype(np.int64) * 100000 + res1["item"]
     assert np.all(np.diff(key) > 0)                                     # ordered by (channel, item)
     good = {int(r["channel"]) for r in res1 if truth.get(int(r["channel"])) == bytes(r["message"])}
