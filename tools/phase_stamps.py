@@ -97,16 +97,16 @@ def main():
     a = ap.parse_args()
 
     scan_seg = segments(listing("scan.hip", "scan_kernelILi6E"))
-    sb_seg = segments(listing("softbits.hip", "softbits_kernelILb1E"))
+    sb_seg = segments(listing("softbits.hip", "softbits_kernelILb1ELb1E"))
     report = []
     P = report.append
-    P("Phase cycles of scan_kernel<6> and softbits_kernel<true> - in-kernel s_memtime stamps (tools/phase_stamps.py, csrc/phase_stamps.h)")
+    P("Phase cycles of scan_kernel<6> and softbits_kernel<true, true> - in-kernel s_memtime stamps (tools/phase_stamps.py, csrc/phase_stamps.h)")
     P("priced = VALU issue cycles of the instructions between the two stamps in the stamps build's listing (tools/asm_mix.py costs)")
     P("")
     P("scan_kernel<6> listing, segments between consecutive s_memtime (stamp order: 0, 11, 1, 2, ... 10, wave-end):")
     for i, s in enumerate(scan_seg):
         P(f"  seg {i:2d}: {fmt_seg(s)}")
-    P("softbits_kernel<true> listing, segments between consecutive s_memtime:")
+    P("softbits_kernel<true, true> listing, segments between consecutive s_memtime:")
     for i, s in enumerate(sb_seg):
         P(f"  seg {i:2d}: {fmt_seg(s)}")
     if a.listing:
@@ -191,7 +191,7 @@ def main():
     self_cost = median((s[:, 11] - s[:, 0]).tolist())
     life = (s[:, 16:24].max(axis=1) - s[:, 0])
     P("")
-    P(f"softbits_kernel<true>: {len(s)} sampled workgroups; stamp cost {self_cost}; median workgroup lifetime {median(life.tolist())} cycles; wave 0 ends at "
+    P(f"softbits_kernel<true, true>: {len(s)} sampled workgroups; stamp cost {self_cost}; median workgroup lifetime {median(life.tolist())} cycles; wave 0 ends at "
       f"{median((s[:, 16] - s[:, 0]).tolist())}, the last wave at {median(life.tolist())}, the first at {median((s[:, 16:24].min(axis=1) - s[:, 0]).tolist())}")
     n2 = s[:, 5]
     # listing order of softbits stamps: 0, 11, 1, 2, [loop: t0, t1, t2], 6, wave-end
