@@ -22,16 +22,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--channels-per-window", type=int, default=48)
+    ap.add_argument("--rank", type=int, default=0, help="input set: bench.make_inputs(rank, 1024) (0 = the bench's own)")
+    ap.add_argument("--seed", type=int, default=99, help="seed of the channel sample")
     a = ap.parse_args()
     import bench
     import parity
     from msk144cudecoder_amd import hipdecoder as hip
     from oracle import oracle as orc
     deep = dict(center=1500.0, width=500.0, step=1.0, depth=6, nbadsync_threshold=3)
-    wins, truth = bench.make_inputs(0, 1024)
+    wins, truth = bench.make_inputs(a.rank, 1024)
     o = orc.Oracle(threads=bench.usable_cores(), **deep)
-    rng = np.random.default_rng(99)
-    tot = dict(windows=0, channels=0, records=0, scan_near_ties=0, nbadsync_marginal=0, bp_marginal=0)
+    rng = np.random.default_rng(a.seed)
+    tot = dict(input_set=a.rank, sample_seed=a.seed, windows=0, channels=0, records=0, scan_near_ties=0, nbadsync_marginal=0, bp_marginal=0)
     t0 = time.time()
     with hip.HipDecoder(channels=1024, max_results=1 << 20, **deep) as prod, hip.HipDecoder(channels=1, **deep) as single:
         for t in range(wins.shape[0]):
